@@ -1,0 +1,200 @@
+/*
+ * ufm_hip.h -- C ABI of libufm_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * UFM dense-correspondence inference hot path.
+ *
+ * The reference (labrat97/UFM) is pure Python; its FFI for this path is "torch ops called from
+ * nn.Module.forward".  Each entry point below replaces the torch op sequence at the cited
+ * reference call site (paths relative to /root/reference/uniflowmatch; lines marked [U] are the
+ * absent third-party `uniception` blocks whose only in-reference trace is the call site).
+ * The reference-side binding a maintainer would add is the ctypes stub shown in INTEGRATION.md
+ * (ufm_amd/hip.py is that stub).
+ *
+ * Conventions
+ *   - plain device pointers + sizes; no torch types.  All pointers are DEVICE pointers unless noted.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
+ *   - every call is asynchronous on `stream`, allocates nothing, never synchronises, and is
+ *     hipGraph-capturable; workspaces are passed in by the caller.
+ *   - return value: 0 on success, negative UFM_ERR_* otherwise; ufm_last_error() gives the text
+ *     (thread-local, host pointer).
+ *   - "rows" are tokens or pixels; activations are row-major [rows][channels] (tokens-major /
+ *     NHWC), so transformer outputs feed the DPT head without any transpose.
+ *   - bf16 = raw uint16_t bit pattern (round-to-nearest-even from fp32).
+ */
+#ifndef UFM_HIP_H
+#define UFM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UFM_OK 0
+#define UFM_ERR_ARG (-1)    /* shape / alignment contract violated (nothing was launched) */
+#define UFM_ERR_LAUNCH (-2) /* hipLaunch reported an error */
+
+#define UFM_ABI_VERSION 1
+
+int ufm_abi_version(void);
+const char* ufm_last_error(void);
+/* Returns the gfx arch string of device 0's code object this library was built for ("gfx950"). */
+const char* ufm_built_arch(void);
+
+/* ---- data types for out_dtype / in_dtype arguments ---- */
+#define UFM_F32 0
+#define UFM_BF16 1
+
+/* ---- activation codes ---- */
+#define UFM_ACT_NONE 0
+#define UFM_ACT_GELU 1 /* exact erf GELU ([U] Mlp.act, encoder + info-sharing blocks) */
+#define UFM_ACT_RELU 2
+
+/* =====================================================================================
+ * Pre-processing.  Replaces models/base.py:215-229 (uint8 -> float/255 -> (x-mean)/std) fused
+ * with the im2col view of the 14x14/14 patch-embed conv ([U] DINOv2 PatchEmbed.proj, call site
+ * models/ufm.py:308-309).  Output row r = (img, py, px) patch; column c*P*P + i*P + j (the
+ * flattened Conv2d weight order), zero padded to `kpad` columns.
+ *   in_layout: 0 = [B][H][W][3] (BHWC), 1 = [B][3][H][W] (BCHW)
+ *   in_dtype : 0 = uint8 (normalise with mean/std), 1 = float32 (affine a*x+b per channel:
+ *              identity or the re-normalisation of base.py:212-213)
+ *   scale3[3], shift3[3]: HOST floats.  uint8 input:  value = (x/255 - shift3[c]) / scale3[c]  with
+ *              shift3 = mean, scale3 = std (the exact expression of base.py:228-229);
+ *              float32 input: value = x*scale3[c] + shift3[c].
+ * ===================================================================================== */
+int ufm_patchify(const void* img, int in_dtype, int in_layout, int B, int H, int W, int patch,
+                 const float* scale3, const float* shift3, void* out, int out_dtype, int kpad,
+                 void* stream);
+
+/* Antialiased bilinear resize, align_corners=False (utils/flow_resizing.py:313-326,
+ * F.interpolate(..., mode="bilinear", antialias=True)); input is normalised like ufm_patchify,
+ * output float32 [B][3][Ho][Wo].  Exact identity when (H,W)==(Ho,Wo). */
+int ufm_resize_antialias(const void* img, int in_dtype, int in_layout, int B, int H, int W,
+                         const float* scale3, const float* shift3, float* out, int Ho, int Wo,
+                         float* tmp /* B*3*H*Wo floats */, void* stream);
+
+/* =====================================================================================
+ * bf16 MFMA GEMM, C[M,N] = A[M,K] . W[N,K]^T with fused epilogue.  Replaces every nn.Linear of
+ * the encoder / info-sharing transformer blocks under the reference's bf16 autocast
+ * (models/base.py:273; [U] Attention.qkv/proj, Mlp.fc1/fc2, proj_embed; patch-embed conv as GEMM).
+ *   v   = acc + bias[n]                       (bias may be NULL)
+ *   v   = act(v)                              (UFM_ACT_*)
+ *   v   = v * gamma[n]                        (LayerScale; gamma may be NULL)
+ *   v  += res[(row % res_row_mod) * ldres + n] (fp32; res may be NULL; res_row_mod<=0 -> row)
+ *   out[orow * ldo + n] = v  as out_dtype, where orow = row, or, if out_row_group>0,
+ *          (row / out_row_group) * (out_row_group + 1) + 1 + row % out_row_group   (cls slot skipped)
+ * res may alias out (in-place residual update).  Requirements: K % 64 == 0, N % 128 == 0,
+ * lda/ldw % 8 == 0, A/W 16-byte aligned.  M arbitrary (tail rows masked).
+ * ===================================================================================== */
+int ufm_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, int N, int K,
+                  const float* bias, int act, const float* gamma, const float* res, int ldres,
+                  int res_row_mod, void* out, int out_dtype, int ldo, int out_row_group,
+                  void* stream);
+
+/* =====================================================================================
+ * LayerNorm over the channel dim, eps inside the sqrt ([U] Block.norm1/norm2, encoder .norm,
+ * info-sharing .norm; nn.LayerNorm(eps=1e-6)).  x: fp32 [*, D] rows of stride ldx.
+ * Output row i is computed from input row (row_index ? row_index[i] : i): this is how the cls
+ * token is dropped and views are re-ordered (models/ufm.py:313, :596-615) without a copy.
+ * ===================================================================================== */
+int ufm_layernorm(const float* x, int ldx, const int32_t* row_index, int rows_out, int D,
+                  const float* weight, const float* bias, float eps, void* out, int out_dtype,
+                  int ldo, void* stream);
+
+/* out[r, :] = src[(r % src_rows), :]  for the rows listed: fills the cls-token rows
+ * (cls_token + pos_embed[0]) of the token buffer: out row = g*(group)+0.  ([U] DINOv2 prepare_tokens) */
+int ufm_fill_rows(float* out, int ldo, int n_groups, int group_stride_rows, const float* src, int D,
+                  void* stream);
+
+/* out[orow(r), :] = a[r, :] + tab[r % tab_mod, :] with the same orow() as ufm_gemm_bf16: fp32 token
+ * assembly (patch tokens + pos-embed, cls slot skipped; view positional encoding) for the
+ * "parity" numerics mode where the GEMM runs on the fp32 conv kernel.  tab may be NULL. */
+int ufm_add_rows(const float* a, int lda, const float* tab, int ldtab, int tab_mod, float* out,
+                 int ldo, int out_row_group, int rows, int D, void* stream);
+
+/* =====================================================================================
+ * Fused multi-head attention forward, non-causal, head_dim 64 ([U] Attention.forward:
+ * softmax(q k^T / sqrt(d)) v; under autocast the reference runs SDPA in bf16).
+ * qkv: bf16 [B*N][3*H*64] laid out (which, head, d) per row = the raw output of the qkv Linear.
+ * out: bf16 [B*N][H*64].  Flash-style: K/V tiles staged in LDS, online softmax in registers,
+ * S = Q K^T and O = P V on MFMA (32x32x16 bf16, fp32 accumulate); N arbitrary (tail masked).
+ * ===================================================================================== */
+int ufm_attention_bf16(const uint16_t* qkv, uint16_t* out, int B, int N, int H, float scale,
+                       void* stream);
+
+/* fp32 variant (numerics mode "parity": exact-fp32 MFMA, same tiling). qkv/out are float. */
+int ufm_attention_f32(const float* qkv, float* out, int B, int N, int H, float scale, void* stream);
+
+/* =====================================================================================
+ * fp32 implicit-GEMM convolution on NHWC activations (exact-fp32 MFMA 32x32x2), the fp32
+ * "island" of the DPT heads (models/ufm.py:635-642; [U] DPTFeature / DPTRegressionProcessor:
+ * 1x1, 3x3/s1, 3x3/s2 Conv2d, ConvTranspose2d with kernel==stride).  Also serves as the fp32
+ * dense GEMM (H=1, W=rows, 1x1) for the "parity" numerics mode.
+ *   in  : fp32 [B][H][W][Cin]         weight: fp32 [Cout][KH][KW][Cin]   (pre-packed)
+ *   out : fp32 [B][Ho][Wo][Cout], Ho = (H + 2*pad - KH)/stride + 1
+ *   v = conv(relu_in ? relu(in) : in) + bias ; v = act(v) ; v *= gamma[n] ; v += res1 + res2
+ *   (res1/res2: fp32, same shape as out, may be NULL, may alias out)
+ *   shuffle > 0: ConvTranspose(k=s=shuffle) mode: weight is [(kh,kw,co)][Cin] with
+ *   Cout = shuffle*shuffle*Co; element (b,y,x,(kh,kw,co)) is stored at
+ *   out[b][y*s+kh][x*s+kw][co]  (KH=KW=1, stride 1).
+ * Requirements: Cin % 32 == 0, Cout % 32 == 0 (Co % 4 == 0 in shuffle mode).
+ * ===================================================================================== */
+int ufm_conv2d_nhwc_f32(const float* in, int B, int H, int W, int Cin, const float* weight,
+                        int Cout, int KH, int KW, int stride, int pad, int relu_in,
+                        const float* bias, int act, const float* gamma, const float* res1,
+                        const float* res2, int shuffle, float* out, int out_dtype_unused,
+                        const float* zero_page /* >=128 B of zeros */, void* stream);
+
+/* Bilinear resize, align_corners=True, NHWC fp32 ([U] FeatureFusionBlock x2 upsample,
+ * DPTRegressionProcessor interpolate-to-target).  src = dst*(in-1)/(out-1).  crop_h/crop_w > 0:
+ * only the top-left crop_h x crop_w of the (Ho, Wo) result is computed and stored (densely) --
+ * the `[:, :, :h, :w]` slice after refinenet4 in the DPT head. */
+int ufm_upsample_bilinear_nhwc(const float* in, int B, int H, int W, int C, float* out, int Ho,
+                               int Wo, int crop_h, int crop_w, void* stream);
+
+/* Head tail: per pixel, y[c] = w[c,:] . x[:] + b[c] over Cin<=64 channels, then the adaptor
+ * ([U] DPTRegressionProcessor.conv2[2] + FlowAdaptor / MaskAdaptor; call sites
+ * models/ufm.py:644-660).  kind[c]: 0 = affine y*a[c]+d[c] (FlowAdaptor), 1 = sigmoid
+ * (MaskAdaptor: writes mask to out, logits to out_logits if non-NULL).
+ * x: fp32 [P][Cin] -> out: fp32 planar [B][Cout][HW] (P = B*HW). Cout <= 4. */
+int ufm_head_tail(const float* x, int P, int HW, int Cin, const float* w, const float* b, int Cout,
+                  const int32_t* kind_host, const float* a_host, const float* d_host, float* out,
+                  float* out_logits, void* stream);
+
+/* =====================================================================================
+ * Post-processing (utils/flow_resizing.py:749-877 unmap_predicted_flow and :955-1010
+ * unmap_predicted_channels, called from models/base.py:279-332): ROI crop, legacy-nearest
+ * resample of the field, bilinear resample of the pixel-centre grid, per-axis coordinate
+ * rescale, offsets, embed into a zero canvas, validity mask.  Regions are
+ * [top,bottom,left,right] HOST ints.  flow: [B][2][h][w] -> out [B][2][H0][W0], valid uint8 [B][H0][W0].
+ * ===================================================================================== */
+int ufm_unmap_flow(const float* flow, int B, int h, int w, const int32_t* rep0, const int32_t* src0,
+                   const int32_t* src1, int H0, int W0, float* out, uint8_t* valid, void* stream);
+int ufm_unmap_channels(const float* chan, int B, int C, int h, int w, const int32_t* rep0,
+                       const int32_t* src0, int H0, int W0, const float* chan_scale_host /*C or NULL*/,
+                       float* out, uint8_t* valid, void* stream);
+
+/* =====================================================================================
+ * UFM-Refine classification refinement, fused (models/ufm.py:1012-1178): for every pixel,
+ * bicubic (A=-0.75, zeros padding, align_corners=False) samples of the view-2 feature map at
+ * flow target +- R, score = q.k / T + bias, softmax / log-softmax over P*P, residual =
+ * sum attn * offset.  Never materialises the (B,H,W,P,P,C) tensor.
+ *   feat: fp32 planar [2B][C][H][W] (first B = view 1); flow [B][2][H][W];
+ *   residual [B][2][H][W]; log_softmax [B][H][W][P][P] (may be NULL).
+ * ===================================================================================== */
+int ufm_refine(const float* flow, const float* feat, int B, int C, int H, int W, int P,
+               float temperature, const float* bias, float* residual, float* log_softmax,
+               void* stream);
+
+/* Pixel shuffle for MLPFeature ([U], call site models/ufm.py:965): x fp32 [B*g*g][C*p*p]
+ * (column = (c, i, j)) -> planar [B][C][g*p][g*p]. */
+int ufm_pixel_shuffle_planar(const float* x, int B, int gh, int gw, int C, int p, float* out,
+                             void* stream);
+
+/* Elementwise helpers used by the host wiring. */
+int ufm_cast_f32_to_bf16(const float* in, uint16_t* out, int64_t n, void* stream);
+int ufm_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UFM_HIP_H */

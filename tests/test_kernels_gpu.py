@@ -1,0 +1,324 @@
+"""Per-kernel parity tests: every C-ABI entry point of libufm_hip.so against a plain PyTorch fp32
+CPU statement of the same op (and the oracle / reference goldens where they exist).
+Run on the GPU box:  python -m pytest tests -m gpu -x -q
+"""
+
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def hip():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from ufm_amd import hip as h
+
+    h.lib()  # fail loudly if the extension is missing
+    return h
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def bf16r(x):
+    return x.to(torch.bfloat16).float()
+
+
+# ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize(
+    "M,N,K,act,use_gamma,use_res,out_bf16,row_mod,row_group",
+    [
+        (300, 256, 128, 0, False, False, True, 0, 0),
+        (300, 256, 128, 1, False, False, True, 0, 0),
+        (257, 128, 64, 0, True, True, False, 0, 0),
+        (2 * 1370, 3072, 1024, 0, False, False, True, 0, 0),
+        (2 * 1370, 1024, 4096, 0, True, True, False, 0, 0),
+        (4 * 16, 128, 640, 0, False, True, False, 16, 16),  # patch-embed style: pos-embed table + cls slot skip
+    ],
+)
+def test_gemm_bf16(hip, M, N, K, act, use_gamma, use_res, out_bf16, row_mod, row_group):
+    A = bf16r(rnd(M, K, seed=1))
+    W = bf16r(rnd(N, K, seed=2, scale=K**-0.5))
+    bias = rnd(N, seed=3, scale=0.1)
+    gamma = 1 + rnd(N, seed=4, scale=0.1) if use_gamma else None
+    rows_res = row_mod if row_mod else M
+    res = rnd(rows_res, N, seed=5) if use_res else None
+    ref = A.double() @ W.double().T + bias.double()
+    if act == 1:
+        ref = F.gelu(ref)
+    if gamma is not None:
+        ref = ref * gamma.double()
+    if res is not None:
+        ref = ref + (res.double()[torch.arange(M) % rows_res] if row_mod else res.double())
+    out_rows = M + M // row_group if row_group else M
+    out = torch.full((out_rows, N), 7.0, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=DEV)
+    res_d = res.to(DEV) if res is not None else None
+    hip.gemm_bf16(
+        A.to(DEV).bfloat16(), W.to(DEV).bfloat16(), M, N, K, out, bias=bias.to(DEV), act=act,
+        gamma=gamma.to(DEV) if gamma is not None else None, res=res_d, res_row_mod=row_mod, out_row_group=row_group,
+    )
+    got = out.float().cpu().double()
+    if row_group:
+        idx = torch.arange(M)
+        orow = (idx // row_group) * (row_group + 1) + 1 + idx % row_group
+        assert torch.all(got[0 :: row_group + 1] == 7.0), "cls slots must be untouched"
+        got = got[orow]
+    tol = 2e-2 if out_bf16 else 2e-4  # bf16 output rounding (|x|~1..4) vs fp32-accumulate error only
+    assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
+def test_gemm_in_place_residual(hip):
+    M, N, K = 200, 128, 64
+    A, W = bf16r(rnd(M, K, seed=1)), bf16r(rnd(N, K, seed=2))
+    x = rnd(M, N, seed=3)
+    xd = x.to(DEV).clone()
+    hip.gemm_bf16(A.to(DEV).bfloat16(), W.to(DEV).bfloat16(), M, N, K, xd, res=xd)
+    assert (xd.cpu() - (x + A @ W.T)).abs().max() < 1e-3
+
+
+def test_gemm_rejects_bad_shapes(hip):
+    A = torch.zeros(64, 96, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        hip.gemm_bf16(A, A, 64, 128, 96, torch.zeros(64, 128, device=DEV))
+
+
+# ----------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("D", [128, 768, 1024])
+@pytest.mark.parametrize("out_bf16", [False, True])
+def test_layernorm(hip, D, out_bf16):
+    rows = 37
+    x = rnd(rows + 5, D, seed=1, scale=3.0) + 0.5
+    w, b = 1 + rnd(D, seed=2, scale=0.1), rnd(D, seed=3, scale=0.1)
+    idx = torch.randperm(rows + 5, generator=torch.Generator().manual_seed(0))[:rows].int()
+    ref = F.layer_norm(x[idx.long()], (D,), w, b, 1e-6)
+    out = torch.empty(rows, D, device=DEV, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    hip.layernorm(x.to(DEV), D, idx.to(DEV), rows, D, w.to(DEV), b.to(DEV), 1e-6, out)
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err <= (3e-2 if out_bf16 else 2e-5)
+
+
+# ----------------------------------------------------------------------------- attention
+def attn_ref(qkv, B, N, H, scale):
+    q, k, v = qkv.double().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    p = torch.softmax((q @ k.transpose(-1, -2)) * scale, dim=-1)
+    return (p @ v).permute(0, 2, 1, 3).reshape(B * N, H * 64)
+
+
+@pytest.mark.parametrize("B,N,H", [(1, 17, 1), (2, 100, 2), (2, 1370, 2), (1, 2738, 3), (1, 64, 1), (1, 129, 1)])
+def test_attention_bf16(hip, B, N, H):
+    qkv = bf16r(rnd(B * N, 3 * H * 64, seed=N, scale=1.5))
+    ref = attn_ref(qkv, B, N, H, 0.125)
+    out = torch.zeros(B * N, H * 64, device=DEV, dtype=torch.bfloat16)
+    hip.attention(qkv.to(DEV).bfloat16(), out, B, N, H, 0.125)
+    err = (out.float().cpu().double() - ref).abs().max().item()
+    assert err <= 2e-2, err  # P and O are rounded to bf16 (8 bits): |O| <~ 1
+
+
+def test_attention_bf16_spike_forces_rescale(hip):
+    """A late key with a huge score forces the online-softmax rescale branch (rule 26)."""
+    B, N, H = 1, 300, 1
+    qkv = bf16r(rnd(N, 192, seed=3, scale=0.5))
+    qkv[:, :64] = bf16r(qkv[:, :64])
+    qkv[250, 64:128] = bf16r(qkv[5, :64] * 30)  # key 250 aligned with query 5
+    ref = attn_ref(qkv, B, N, H, 0.125)
+    out = torch.zeros(N, 64, device=DEV, dtype=torch.bfloat16)
+    hip.attention(qkv.to(DEV).bfloat16(), out, B, N, H, 0.125)
+    assert (out.float().cpu().double() - ref).abs().max().item() <= 2e-2
+
+
+@pytest.mark.parametrize("B,N,H", [(1, 17, 1), (2, 200, 2), (1, 1370, 1)])
+def test_attention_f32(hip, B, N, H):
+    qkv = rnd(B * N, 3 * H * 64, seed=N, scale=1.5)
+    ref = attn_ref(qkv, B, N, H, 0.125)
+    out = torch.zeros(B * N, H * 64, device=DEV)
+    hip.attention(qkv.to(DEV), out, B, N, H, 0.125)
+    assert (out.cpu().double() - ref).abs().max().item() <= 2e-5
+
+
+# ----------------------------------------------------------------------------- conv (fp32 MFMA)
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize(
+    "B,H,W,Cin,Cout,k,stride,pad,relu_in,act,nres",
+    [
+        (2, 9, 11, 32, 32, 3, 1, 1, False, 0, 0),
+        (1, 37, 37, 64, 128, 3, 1, 1, True, 0, 2),
+        (2, 37, 37, 96, 64, 3, 2, 1, False, 0, 0),
+        (1, 20, 13, 128, 96, 1, 1, 0, False, 2, 1),
+        (1, 30, 30, 256, 256, 3, 1, 1, True, 0, 1),
+    ],
+)
+def test_conv2d(hip, B, H, W, Cin, Cout, k, stride, pad, relu_in, act, nres):
+    x = rnd(B, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5)
+    b = rnd(Cout, seed=3, scale=0.1)
+    ref = F.conv2d(F.relu(x) if relu_in else x, w, b, stride=stride, padding=pad)
+    if act == 2:
+        ref = F.relu(ref)
+    res = [rnd(*ref.shape, seed=10 + i) for i in range(nres)]
+    for r in res:
+        ref = ref + r
+    Ho, Wo = ref.shape[2:]
+    out = torch.zeros(B, Ho, Wo, Cout, device=DEV)
+    zero = torch.zeros(64, device=DEV)
+    resd = [nhwc(r).to(DEV) for r in res] + [None, None]
+    hip.conv2d(nhwc(x).to(DEV), B, H, W, Cin, w.permute(0, 2, 3, 1).contiguous().to(DEV), Cout, k, k, stride, pad, out, zero,
+               relu_in=relu_in, bias=b.to(DEV), act=act, res1=resd[0], res2=resd[1])
+    err = (out.cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("s,Cin,Co", [(4, 32, 32), (2, 64, 48)])
+def test_conv_transpose_as_shuffle(hip, s, Cin, Co):
+    B, H, W = 2, 5, 7
+    x = rnd(B, Cin, H, W, seed=1)
+    wt = rnd(Cin, Co, s, s, seed=2, scale=Cin**-0.5)
+    b = rnd(Co, seed=3, scale=0.1)
+    ref = F.conv_transpose2d(x, wt, b, stride=s)
+    wp = wt.permute(2, 3, 1, 0).reshape(s * s * Co, Cin).contiguous()
+    out = torch.zeros(B, H * s, W * s, Co, device=DEV)
+    zero = torch.zeros(64, device=DEV)
+    hip.conv2d(nhwc(x).to(DEV), B, H, W, Cin, wp.to(DEV), s * s * Co, 1, 1, 1, 0, out, zero, bias=b.to(DEV), shuffle=s)
+    assert (out.cpu().permute(0, 3, 1, 2) - ref).abs().max().item() <= 2e-5
+
+
+def test_conv_as_dense_gemm(hip):
+    M, K, N = 333, 128, 384
+    a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K**-0.5)
+    out = torch.zeros(M, N, device=DEV)
+    hip.conv2d(a.to(DEV), 1, 1, M, K, w.to(DEV), N, 1, 1, 1, 0, out, torch.zeros(64, device=DEV), act=1)
+    assert (out.cpu() - F.gelu(a @ w.T)).abs().max().item() <= 2e-5
+
+
+# ----------------------------------------------------------------------------- pointwise
+@pytest.mark.parametrize("Ho,Wo,crop", [(20, 26, None), (37, 37, None), (14, 18, (13, 17))])
+def test_upsample(hip, Ho, Wo, crop):
+    B, H, W, Cc = 2, 7, 9, 8
+    x = rnd(B, Cc, H, W, seed=1)
+    ref = F.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=True)
+    ch, cw = crop if crop else (Ho, Wo)
+    ref = ref[:, :, :ch, :cw]
+    out = torch.zeros(B, ch, cw, Cc, device=DEV)
+    hip.upsample_bilinear(nhwc(x).to(DEV), B, H, W, Cc, out, Ho, Wo, *(crop or (0, 0)))
+    assert (out.cpu().permute(0, 3, 1, 2) - ref).abs().max().item() <= 1e-5
+
+
+def test_upsample_scale2_matches_scale_factor(hip):
+    x = rnd(1, 4, 19, 19, seed=2)
+    ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    out = torch.zeros(1, 38, 38, 4, device=DEV)
+    hip.upsample_bilinear(nhwc(x).to(DEV), 1, 19, 19, 4, out, 38, 38)
+    assert (out.cpu().permute(0, 3, 1, 2) - ref).abs().max().item() <= 1e-5
+
+
+def test_head_tail(hip):
+    B, HW, Cin = 2, 35, 32
+    x, w, b = rnd(B * HW, Cin, seed=1), rnd(3, Cin, seed=2), rnd(3, seed=3)
+    y = x @ w.T + b
+    out = torch.zeros(B, 3, HW, device=DEV)
+    logits = torch.zeros(B, 3, HW, device=DEV)
+    hip.head_tail(x.to(DEV), B * HW, HW, Cin, w.to(DEV), b.to(DEV), 3, [0, 0, 1], [2.0, 0.5, 1.0], [0.1, -0.2, 0.0], out, logits)
+    yy = y.reshape(B, HW, 3).permute(0, 2, 1)
+    assert (out.cpu()[:, 0] - (yy[:, 0] * 2.0 + 0.1)).abs().max() <= 1e-5
+    assert (out.cpu()[:, 1] - (yy[:, 1] * 0.5 - 0.2)).abs().max() <= 1e-5
+    assert (out.cpu()[:, 2] - torch.sigmoid(yy[:, 2])).abs().max() <= 1e-6
+    assert (logits.cpu()[:, 2] - yy[:, 2]).abs().max() <= 1e-5
+
+
+def test_patchify_u8_and_f32(hip):
+    from oracle import uniception_ref as U
+
+    B, H, W, P = 2, 28, 42, 14
+    g = torch.Generator().manual_seed(0)
+    img = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, generator=g)
+    n = U.IMAGE_NORMALIZATION_DICT["dinov2"]
+    norm = (img.permute(0, 3, 1, 2).float() / 255.0 - n.mean.view(1, 3, 1, 1)) / n.std.view(1, 3, 1, 1)
+    ref = F.unfold(norm, kernel_size=P, stride=P).transpose(1, 2).reshape(-1, 3 * P * P)  # (c,i,j) column order
+    out = torch.full((ref.shape[0], 640), 5.0, device=DEV)
+    hip.patchify(img.to(DEV), 0, B, H, W, P, n.std.tolist(), n.mean.tolist(), out, 640)
+    assert torch.equal(out.cpu()[:, :588], ref)  # same fp32 expression -> bit exact
+    assert torch.all(out.cpu()[:, 588:] == 0)
+    out2 = torch.zeros(ref.shape[0], 640, device=DEV, dtype=torch.bfloat16)
+    hip.patchify(norm.contiguous().to(DEV), 1, B, H, W, P, [1, 1, 1], [0, 0, 0], out2, 640)
+    assert torch.equal(out2.cpu()[:, :588], ref.bfloat16())
+
+
+@pytest.mark.parametrize("src_hw,dst_hw", [((75, 100), (42, 56)), ((30, 40), (56, 70)), ((56, 56), (56, 56)), ((1080, 607), (518, 518))])
+def test_resize_antialias(hip, src_hw, dst_hw):
+    B = 1
+    x = rnd(B, 3, *src_hw, seed=4)
+    ref = F.interpolate(x, size=dst_hw, mode="bilinear", align_corners=False, antialias=True)
+    out = torch.zeros(B, 3, *dst_hw, device=DEV)
+    tmp = torch.zeros(B * 3 * src_hw[0] * dst_hw[1], device=DEV)
+    hip.resize_antialias(x.to(DEV), 1, B, src_hw[0], src_hw[1], [1, 1, 1], [0, 0, 0], out, dst_hw[0], dst_hw[1], tmp)
+    err = (out.cpu() - ref).abs().max().item()
+    assert err <= (0.0 if src_hw == dst_hw else 5e-6), err
+
+
+@pytest.mark.parametrize("name", ["unmap_full.npz", "unmap_crop.npz"])
+def test_unmap_vs_reference_goldens(hip, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name))
+    fl, ch = torch.from_numpy(g["flow_in"]), torch.from_numpy(g["chan_in"])
+    B, _, h, w = fl.shape
+    H0, W0 = (int(v) for v in g["shape0"])
+    fo = torch.full((B, 2, H0, W0), 9.0, device=DEV)
+    fv = torch.zeros(B, H0, W0, dtype=torch.uint8, device=DEV)
+    hip.unmap_flow(fl.to(DEV), B, h, w, g["rep0"].tolist(), g["src0"].tolist(), g["src1"].tolist(), H0, W0, fo, fv)
+    # coordinates are O(100) px in fp32 (ulp 7.6e-6); two independent fp32 evaluations differ by a few ulp
+    assert np.abs(fo.cpu().numpy() - g["flow_out"]).max() <= 5e-5
+    assert np.array_equal(fv.cpu().numpy().astype(bool), g["flow_valid"])
+    co = torch.full((B, 3, H0, W0), 9.0, device=DEV)
+    hip.unmap_channels(ch.to(DEV), B, 3, h, w, g["rep0"].tolist(), g["src0"].tolist(), H0, W0, co)
+    assert np.array_equal(co.cpu().numpy(), g["chan_out"])
+
+
+@pytest.mark.parametrize("name", ["refine_p5.npz", "refine_p3.npz"])
+def test_refine_vs_reference_goldens(hip, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name))
+    flow, feats = torch.from_numpy(g["flow"]), torch.from_numpy(g["feats"])
+    B, _, H, W = flow.shape
+    P = int(g["patch"])
+    res = torch.zeros(B, 2, H, W, device=DEV)
+    logp = torch.zeros(B, H, W, P, P, device=DEV)
+    hip.refine(flow.to(DEV), feats.to(DEV), B, feats.shape[1], H, W, P, float(g["temperature"]), torch.from_numpy(g["bias"]).to(DEV), res, logp)
+    assert np.abs(res.cpu().numpy() - g["residual"]).max() <= 2e-4
+    assert np.abs(logp.cpu().numpy() - g["log_softmax"]).max() <= 2e-4
+
+
+def test_pixel_shuffle_and_misc(hip):
+    B, gh, gw, Cc, p = 2, 3, 4, 5, 14
+    x = rnd(B * gh * gw, Cc * p * p, seed=1)
+    ref = F.pixel_shuffle(x.reshape(B, gh, gw, Cc * p * p).permute(0, 3, 1, 2), p)
+    out = torch.zeros(B, Cc, gh * p, gw * p, device=DEV)
+    hip.pixel_shuffle_planar(x.to(DEV), B, gh, gw, Cc, p, out)
+    assert torch.equal(out.cpu(), ref)
+    a, b = rnd(1024, seed=2), rnd(1024, seed=3)
+    o = torch.zeros(1024, device=DEV)
+    hip.add_f32(a.to(DEV), b.to(DEV), o)
+    assert torch.equal(o.cpu(), a + b)
+    ob = torch.zeros(1024, device=DEV, dtype=torch.bfloat16)
+    hip.cast_bf16(a.to(DEV), ob)
+    assert torch.equal(ob.cpu(), a.bfloat16())
+    rows, D, grp = 8, 16, 4
+    t, tab = rnd(rows, D, seed=5), rnd(grp, D, seed=6)
+    oo = torch.full((rows + rows // grp, D), 3.0, device=DEV)
+    hip.add_rows(t.to(DEV), D, tab.to(DEV), grp, oo, D, grp, rows, D)
+    idx = torch.arange(rows)
+    orow = (idx // grp) * (grp + 1) + 1 + idx % grp
+    assert torch.equal(oo.cpu()[orow], t + tab[idx % grp])
+    fr = torch.zeros(10, D, device=DEV)
+    hip.fill_rows(fr, D, 2, 5, tab[0].contiguous().to(DEV), D)
+    assert torch.equal(fr.cpu()[0], tab[0]) and torch.equal(fr.cpu()[5], tab[0]) and fr.cpu()[1:5].abs().sum() == 0

@@ -1,0 +1,223 @@
+// Flash-style multi-head attention forward for head_dim 64, bf16 operands, fp32 accumulate.
+//
+// gfx950 design (cdna_hip_programming.md Appendix B "Fused attention prefill", section 3
+// "An accumulator tile as the next MFMA's operand", T2, T10):
+//   * workgroup = 4 waves = 128 query rows of one (image, head); each wave owns 32 query rows
+//     and streams all keys in 64-key tiles shared through LDS (K and V: 8 KiB each, 2 stages).
+//   * swapped QK^T: S^T[key][q] = K . Q^T with v_mfma_f32_32x32x16_bf16, so a lane holds ONE
+//     query column and 16 keys per 32-key tile: the online-softmax max/sum are in-lane plus a
+//     single lane^32 exchange; the rescale factor is a per-lane scalar.
+//   * P never leaves registers: the S^T accumulator, converted pairwise to bf16, IS the B operand
+//     of O^T[d][q] += V^T[d][key] . P^T[key][q]; V^T fragments come from a row-major V tile via
+//     ds_read_b64_tr_b16 (hardware transpose) in the accumulator's permuted key order.
+//   * K tile: 128-B rows, chunk XOR ((key>>1)&7) -> conflict-free ds_read_b128 for the 32-row
+//     operand; V tile: chunk XOR (((key>>1)&1)<<2) -> conflict-free transposed reads.
+//   * K/V: global -> registers -> LDS (register staging, T14): next tile's loads are issued
+//     before this tile's MFMAs, written to the other stage afterwards; one barrier per tile.
+//   * exp2 with scale*log2(e) folded into one FMA per score; ragged tail masked in the last tile.
+#include "common.h"
+
+namespace {
+
+constexpr int QB = 128;  // query rows per workgroup
+constexpr int KB = 64;   // keys per tile
+constexpr int STAGE = 16384;
+constexpr float NEG_BIG = -1.0e30f;
+
+typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+
+__device__ __forceinline__ bf16x4 tr_read(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_ptr)LDS_PTR(p));
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
+                                                           int N, int H, float c) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // 1-D grid, XCD-aware: all query blocks of one (image, head) are consecutive logical ids and
+    // therefore share one XCD's L2 for their K/V stream (T1).
+    const int nqb = (N + QB - 1) / QB;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int qblk = lid % nqb, head = (lid / nqb) % H, b = lid / (nqb * H);
+    const int ld = 3 * H * 64;
+    const uint16_t* base = qkv + (size_t)b * N * ld + head * 64;
+    const uint16_t* kp = base + H * 64;
+    const uint16_t* vp = base + 2 * H * 64;
+    const int ql = lane & 31, hh = lane >> 5;
+    const int q = qblk * QB + wave * 32 + ql;
+
+    bf16x8 qf[4];
+    {
+        const uint16_t* qr = base + (size_t)min(q, N - 1) * ld + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qr + 16 * s);
+    }
+
+    // staging: thread -> rows (tid>>3) and (tid>>3)+32 of the tile, 16-byte chunk tid&7
+    const int srow = tid >> 3, schunk = tid & 7;
+    int k_lds[2], v_lds[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = srow + 32 * i;
+        k_lds[i] = r * 128 + ((schunk ^ ((r >> 1) & 7)) << 4);
+        v_lds[i] = 8192 + r * 128 + ((schunk ^ (((r >> 1) & 1) << 2)) << 4);
+    }
+    u32x4 kreg[2], vreg[2];
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const size_t row = (size_t)min(t * KB + srow + 32 * i, N - 1);  // clamp: masked below
+            kreg[i] = *(const u32x4*)(kp + row * ld + schunk * 8);
+            vreg[i] = *(const u32x4*)(vp + row * ld + schunk * 8);
+        }
+    };
+    auto store_tile = [&](int stage) {
+        char* s = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *(u32x4*)(s + k_lds[i]) = kreg[i];
+            *(u32x4*)(s + v_lds[i]) = vreg[i];
+        }
+    };
+
+    // fragment read offsets
+    int k_off[2][4];  // [key tile][k-step]
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int key = kt * 32 + ql;
+            k_off[kt][s] = key * 128 + (((2 * s + hh) ^ ((key >> 1) & 7)) << 4);
+        }
+    // V^T transposed-read lane address: group G = lane>>4, i = lane&15: row kb + (i>>2), cols d0 + 4*(i&3)
+    const int ti = lane & 15, tq = ti >> 2, tp = ti & 3;
+    const int tdc = 16 * ((lane >> 4) & 1) + 4 * tp;  // d column within the 32-wide d tile
+    int v_off[2][2][2][2];                            // [dt][kt][s2][lo/hi]
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int row = kt * 32 + 16 * s2 + 4 * hh + 8 * e + tq;
+                    const int dcol = dt * 32 + tdc;
+                    v_off[dt][kt][s2][e] = 8192 + row * 128 + ((((dcol >> 3)) ^ (((row >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1);
+                }
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float m_run = NEG_BIG, l_run = 0.f;
+
+    const int nt = (N + KB - 1) / KB;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) load_tile(t + 1);
+        const char* s = smem + (t & 1) * STAGE;
+
+        // ---- S^T = K . Q^T ----
+        f32x16 st[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(s + k_off[kt][ks]);
+                st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kt], 0, 0, 0);
+            }
+        }
+        if ((t + 1) * KB > N) {  // ragged tail (block-uniform branch)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * KB + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (key >= N) st[kt][r] = NEG_BIG;
+                }
+        }
+        // ---- online softmax (per lane = per query column) ----
+        float mloc = st[0][0];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[kt][r]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        m_run = m_new;
+        const float mc = m_new * c;
+        float lsum = 0.f;
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            unsigned pk[8];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], c, -mc));
+                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r + 1], c, -mc));
+                lsum += p0 + p1;
+                pk[r >> 1] = pack_bf16x2(p0, p1);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                u32x4 w = {pk[4 * s2], pk[4 * s2 + 1], pk[4 * s2 + 2], pk[4 * s2 + 3]};
+                pf[kt][s2] = __builtin_bit_cast(bf16x8, w);
+            }
+        }
+        l_run = l_run * alpha + lsum;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+
+        // ---- O^T += V^T . P^T ----
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x4 lo = tr_read(s + v_off[dt][kt][s2][0]);
+                    const bf16x4 hi = tr_read(s + v_off[dt][kt][s2][1]);
+                    const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][s2], oacc[dt], 0, 0, 0);
+                }
+
+        if (t + 1 < nt) store_tile((t + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: O[q][d] = O^T[d][q] / l ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q < N) {
+        uint16_t* orow = out + ((size_t)b * N + q) * (H * 64) + head * 64 + 4 * hh;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 pk = {pack_bf16x2(oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv),
+                            pack_bf16x2(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv)};
+                *(u32x2*)(orow + dt * 32 + 8 * g) = pk;
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int ufm_attention_bf16(const uint16_t* qkv, uint16_t* out, int B, int N, int H, float scale, void* stream) {
+    UFM_REQUIRE(qkv && out, "ufm_attention_bf16: null pointer");
+    UFM_REQUIRE(B > 0 && N > 0 && H > 0 && (int64_t)((N + QB - 1) / QB) * H * B < (1ll << 31), "ufm_attention_bf16: bad shape B=%d N=%d H=%d", B, N, H);
+    UFM_REQUIRE(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 8) == 0, "ufm_attention_bf16: misaligned pointer");
+    dim3 grid(((N + QB - 1) / QB) * H * B), block(256);
+    hipLaunchKernelGGL(attn_bf16_kernel, grid, block, 0, (hipStream_t)stream, qkv, out, N, H, scale * 1.44269504088896340736f);
+    UFM_CHECK_LAUNCH("ufm_attention_bf16");
+    return UFM_OK;
+}

@@ -1,0 +1,389 @@
+// HBM-bound pointwise / gather kernels of the UFM hot path: patchify (+normalise), bilinear
+// upsample (align_corners=True, NHWC), head tail (1x1 conv + adaptor), flow / channel un-mapping,
+// pixel shuffle, casts.  All are coalesced 8-16 B per lane, grid-strided, one pass over the data.
+#include "common.h"
+
+namespace {
+
+struct Affine3 {
+    float scale[3];
+    float shift[3];
+};
+
+__device__ __forceinline__ float load_px(const void* img, int in_dtype, int in_layout, int b, int c, int y, int x,
+                                         int H, int W) {
+    size_t idx = in_layout == 0 ? (((size_t)b * H + y) * W + x) * 3 + c : (((size_t)b * 3 + c) * H + y) * W + x;
+    return in_dtype == 0 ? (float)((const uint8_t*)img)[idx] : ((const float*)img)[idx];
+}
+
+// out[(b,py,px)][c*P*P + i*P + j], 4 consecutive k per thread.
+template <int OUT_BF16>
+__global__ __launch_bounds__(256) void patchify_kernel(const void* img, int in_dtype, int in_layout, int B, int H,
+                                                       int W, int P, Affine3 af, void* out, int kpad) {
+    const int gh = H / P, gw = W / P;
+    const int kq = kpad >> 2;
+    const size_t total = (size_t)B * gh * gw * kq;
+    const int kreal = 3 * P * P;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int k4 = (int)(t % kq);
+        const size_t row = t / kq;
+        const int px = (int)(row % gw);
+        const int py = (int)((row / gw) % gh);
+        const int b = (int)(row / ((size_t)gw * gh));
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k4 * 4 + e;
+            if (k < kreal) {
+                const int c = k / (P * P), ij = k - c * P * P, i = ij / P, j = ij - i * P;
+                const float raw = load_px(img, in_dtype, in_layout, b, c, py * P + i, px * P + j, H, W);
+                v[e] = in_dtype == 0 ? (raw / 255.0f - af.shift[c]) / af.scale[c]  // (x/255 - mean)/std, base.py:228
+                                     : raw * af.scale[c] + af.shift[c];
+            } else {
+                v[e] = 0.f;
+            }
+        }
+        if (OUT_BF16) {
+            u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            *(u32x2*)((uint16_t*)out + row * kpad + k4 * 4) = pk;
+        } else {
+            *(f32x4*)((float*)out + row * kpad + k4 * 4) = f32x4{v[0], v[1], v[2], v[3]};
+        }
+    }
+}
+
+// align_corners=True bilinear, NHWC, float4 over channels.
+// (Ho, Wo) is the stored extent; sy/sx come from the FULL output size (a cropped store, DPT refinenet4).
+__global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ in, int B, int H, int W, int C,
+                                                       float* __restrict__ out, int Ho, int Wo, float sy, float sx) {
+    const int cq = C >> 2;
+    const size_t total = (size_t)B * Ho * Wo * cq;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(t % cq);
+        size_t pix = t / cq;
+        const int ox = (int)(pix % Wo);
+        const int oy = (int)((pix / Wo) % Ho);
+        const int b = (int)(pix / ((size_t)Wo * Ho));
+        const float fy = sy * oy, fx = sx * ox;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+        const float ly1 = fy - y0, lx1 = fx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        const float* base = in + (size_t)b * H * W * C + c4 * 4;
+        const f32x4 v00 = *(const f32x4*)(base + ((size_t)y0 * W + x0) * C);
+        const f32x4 v01 = *(const f32x4*)(base + ((size_t)y0 * W + x1) * C);
+        const f32x4 v10 = *(const f32x4*)(base + ((size_t)y1 * W + x0) * C);
+        const f32x4 v11 = *(const f32x4*)(base + ((size_t)y1 * W + x1) * C);
+        f32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = ly0 * (lx0 * v00[j] + lx1 * v01[j]) + ly1 * (lx0 * v10[j] + lx1 * v11[j]);
+        *(f32x4*)(out + pix * C + c4 * 4) = r;
+    }
+}
+
+struct TailArgs {
+    int kind[4];
+    float a[4];
+    float d[4];
+};
+
+// one thread per pixel; x row is Cin floats (Cin % 4 == 0, <= 64); w/b from global (L1/L2 resident).
+__global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict__ x, int P, int HW, int Cin,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                        int Cout, TailArgs ta, float* __restrict__ out,
+                                                        float* __restrict__ out_logits) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* xr = x + (size_t)p * Cin;
+        for (int k = 0; k < Cin; k += 4) {
+            const f32x4 xv = *(const f32x4*)(xr + k);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c < Cout) {
+                    const f32x4 wv = *(const f32x4*)(w + c * Cin + k);
+                    acc[c] += xv[0] * wv[0];
+                    acc[c] += xv[1] * wv[1];
+                    acc[c] += xv[2] * wv[2];
+                    acc[c] += xv[3] * wv[3];
+                }
+            }
+        }
+        const int b = p / HW, q = p - b * HW;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < Cout) {
+                const float y = acc[c] + bias[c];
+                const size_t o = ((size_t)b * Cout + c) * HW + q;
+                if (ta.kind[c] == 1) {
+                    out[o] = 1.0f / (1.0f + expf(-y));
+                    if (out_logits) out_logits[o] = y;
+                } else {
+                    out[o] = y * ta.a[c] + ta.d[c];
+                }
+            }
+        }
+    }
+}
+
+struct UnmapArgs {
+    int rep0[4], src0[4], src1[4];
+    float sscale[2], tscale[2];  // (x, y) -- float32 ratios, flow_resizing.py:832-853
+    float cscale[4];
+};
+
+// torch bilinear (align_corners=False, no antialias) source index + weights for one axis
+__device__ __forceinline__ void lin_coef(int dst, float scale, int in_size, int& i0, int& i1, float& l0, float& l1) {
+    float src = scale * (dst + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    i0 = (int)src;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = src - i0;
+    l0 = 1.f - l1;
+}
+
+__global__ __launch_bounds__(256) void unmap_flow_kernel(const float* __restrict__ flow, int B, int h, int w,
+                                                         UnmapArgs ua, int H0, int W0, float* __restrict__ out,
+                                                         uint8_t* __restrict__ valid) {
+    const int rh = ua.rep0[1] - ua.rep0[0], rw = ua.rep0[3] - ua.rep0[2];
+    const int sh = ua.src0[1] - ua.src0[0], sw = ua.src0[3] - ua.src0[2];
+    const float by = (float)rh / sh, bx = (float)rw / sw;  // bilinear + legacy-nearest scale = in/out
+    const size_t total = (size_t)B * H0 * W0;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(t % W0), y = (int)((t / W0) % H0), b = (int)(t / ((size_t)W0 * H0));
+        float fx = 0.f, fy = 0.f;
+        const bool in = y >= ua.src0[0] && y < ua.src0[1] && x >= ua.src0[2] && x < ua.src0[3];
+        if (in) {
+            const int yy = y - ua.src0[0], xx = x - ua.src0[2];
+            int iy0, iy1, ix0, ix1;
+            float ly0, ly1, lx0, lx1;
+            lin_coef(yy, by, rh, iy0, iy1, ly0, ly1);
+            lin_coef(xx, bx, rw, ix0, ix1, lx0, lx1);
+            // pixel-centre grid (flow_resizing.py:788-800) interpolated like F.interpolate does it (2-D lerp)
+            const float gx0 = ix0 + 0.5f, gx1 = ix1 + 0.5f, gy0 = iy0 + 0.5f, gy1 = iy1 + 0.5f;
+            float sx = ly0 * (lx0 * gx0 + lx1 * gx1) + ly1 * (lx0 * gx0 + lx1 * gx1);
+            float sy = ly0 * (lx0 * gy0 + lx1 * gy0) + ly1 * (lx0 * gy1 + lx1 * gy1);
+            // legacy nearest: src = min(floor(dst * scale), in - 1)
+            const int ny = min((int)floorf(yy * by), rh - 1), nx = min((int)floorf(xx * bx), rw - 1);
+            const size_t fo = ((size_t)b * 2 * h + (ua.rep0[0] + ny)) * w + ua.rep0[2] + nx;
+            float tx = flow[fo] + sx, ty = flow[fo + (size_t)h * w] + sy;
+            sx = sx * ua.sscale[0];
+            sy = sy * ua.sscale[1];
+            tx = tx * ua.tscale[0];
+            ty = ty * ua.tscale[1];
+            sx += (float)ua.src0[2];
+            sy += (float)ua.src0[0];
+            tx += (float)ua.src1[2];
+            ty += (float)ua.src1[0];
+            fx = tx - sx;
+            fy = ty - sy;
+        }
+        const size_t o = ((size_t)b * 2 * H0 + y) * W0 + x;
+        out[o] = fx;
+        out[o + (size_t)H0 * W0] = fy;
+        if (valid) valid[t] = in ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void unmap_channels_kernel(const float* __restrict__ chan, int B, int C, int h, int w,
+                                                             UnmapArgs ua, int H0, int W0, int use_scale,
+                                                             float* __restrict__ out, uint8_t* __restrict__ valid) {
+    const int rh = ua.rep0[1] - ua.rep0[0], rw = ua.rep0[3] - ua.rep0[2];
+    const int sh = ua.src0[1] - ua.src0[0], sw = ua.src0[3] - ua.src0[2];
+    const float by = (float)rh / sh, bx = (float)rw / sw;
+    const size_t total = (size_t)B * H0 * W0;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(t % W0), y = (int)((t / W0) % H0), b = (int)(t / ((size_t)W0 * H0));
+        const bool in = y >= ua.src0[0] && y < ua.src0[1] && x >= ua.src0[2] && x < ua.src0[3];
+        int ny = 0, nx = 0;
+        if (in) {
+            ny = min((int)floorf((y - ua.src0[0]) * by), rh - 1);
+            nx = min((int)floorf((x - ua.src0[2]) * bx), rw - 1);
+        }
+        for (int c = 0; c < C; ++c) {
+            float v = 0.f;
+            if (in) {
+                v = chan[(((size_t)b * C + c) * h + ua.rep0[0] + ny) * w + ua.rep0[2] + nx];
+                if (use_scale) v *= ua.cscale[c];
+            }
+            out[(((size_t)b * C + c) * H0 + y) * W0 + x] = v;
+        }
+        if (valid) valid[t] = in ? 1 : 0;
+    }
+}
+
+// x [B*gh*gw][C*p*p] (col = (c,i,j)) -> out planar [B][C][gh*p][gw*p]
+__global__ __launch_bounds__(256) void pixel_shuffle_kernel(const float* __restrict__ x, int B, int gh, int gw, int C,
+                                                            int p, float* __restrict__ out) {
+    const int Ho = gh * p, Wo = gw * p;
+    const size_t total = (size_t)B * C * Ho * Wo;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(t % Wo), oy = (int)((t / Wo) % Ho);
+        const int c = (int)((t / ((size_t)Wo * Ho)) % C), b = (int)(t / ((size_t)Wo * Ho * C));
+        const int gy = oy / p, i = oy - gy * p, gx = ox / p, j = ox - gx * p;
+        out[t] = x[(((size_t)b * gh + gy) * gw + gx) * ((size_t)C * p * p) + (c * p + i) * p + j];
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, size_t n4) {
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 v = *(const f32x4*)(in + t * 4);
+        u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        *(u32x2*)(out + t * 4) = pk;
+    }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ out, size_t n4) {
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 va = *(const f32x4*)(a + t * 4), vb = *(const f32x4*)(b + t * 4);
+        *(f32x4*)(out + t * 4) = va + vb;
+    }
+}
+
+// out[orow(r)][:] = a[r][:] + tab[r % tab_mod][:]  (fp32 token assembly for the "parity" numerics mode)
+__global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__ a, int lda, const float* __restrict__ tab,
+                                                       int ldtab, int tab_mod, float* __restrict__ out, int ldo,
+                                                       int out_row_group, int rows, int D) {
+    const int dq = D >> 2;
+    const size_t total = (size_t)rows * dq;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % dq);
+        const int r = (int)(t / dq);
+        const int orow = out_row_group > 0 ? (r / out_row_group) * (out_row_group + 1) + 1 + r % out_row_group : r;
+        f32x4 v = *(const f32x4*)(a + (size_t)r * lda + c * 4);
+        if (tab) v += *(const f32x4*)(tab + (size_t)(tab_mod > 0 ? r % tab_mod : r) * ldtab + c * 4);
+        *(f32x4*)(out + (size_t)orow * ldo + c * 4) = v;
+    }
+}
+
+inline dim3 stream_grid(size_t work_items) {
+    size_t blocks = (work_items + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;  // Guideline 11: cap and grid-stride
+    if (blocks < 1) blocks = 1;
+    return dim3((unsigned)blocks);
+}
+
+}  // namespace
+
+extern "C" int ufm_patchify(const void* img, int in_dtype, int in_layout, int B, int H, int W, int patch,
+                            const float* scale3, const float* shift3, void* out, int out_dtype, int kpad,
+                            void* stream) {
+    UFM_REQUIRE(img && out && scale3 && shift3, "ufm_patchify: null pointer");
+    UFM_REQUIRE(B > 0 && patch > 0 && H % patch == 0 && W % patch == 0, "ufm_patchify: H=%d W=%d not multiples of patch=%d", H, W, patch);
+    UFM_REQUIRE(kpad % 4 == 0 && kpad >= 3 * patch * patch, "ufm_patchify: kpad=%d too small / not multiple of 4", kpad);
+    UFM_REQUIRE((in_dtype == 0 || in_dtype == 1) && (in_layout == 0 || in_layout == 1), "ufm_patchify: bad dtype/layout");
+    Affine3 af;
+    for (int c = 0; c < 3; ++c) {
+        af.scale[c] = scale3[c];
+        af.shift[c] = shift3[c];
+    }
+    const size_t total = (size_t)B * (H / patch) * (W / patch) * (kpad / 4);
+    if (out_dtype == UFM_BF16)
+        hipLaunchKernelGGL(patchify_kernel<1>, stream_grid(total), dim3(256), 0, (hipStream_t)stream, img, in_dtype, in_layout, B, H, W, patch, af, out, kpad);
+    else
+        hipLaunchKernelGGL(patchify_kernel<0>, stream_grid(total), dim3(256), 0, (hipStream_t)stream, img, in_dtype, in_layout, B, H, W, patch, af, out, kpad);
+    UFM_CHECK_LAUNCH("ufm_patchify");
+    return UFM_OK;
+}
+
+extern "C" int ufm_upsample_bilinear_nhwc(const float* in, int B, int H, int W, int C, float* out, int Ho, int Wo,
+                                          int crop_h, int crop_w, void* stream) {
+    UFM_REQUIRE(in && out, "ufm_upsample_bilinear_nhwc: null pointer");
+    UFM_REQUIRE(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && C % 4 == 0, "ufm_upsample_bilinear_nhwc: bad shape");
+    UFM_REQUIRE(crop_h >= 0 && crop_h <= Ho && crop_w >= 0 && crop_w <= Wo, "ufm_upsample_bilinear_nhwc: bad crop");
+    const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+    const float sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const int Hs = crop_h > 0 ? crop_h : Ho, Ws = crop_w > 0 ? crop_w : Wo;
+    const size_t total = (size_t)B * Hs * Ws * (C / 4);
+    hipLaunchKernelGGL(upsample_kernel, stream_grid(total), dim3(256), 0, (hipStream_t)stream, in, B, H, W, C, out, Hs, Ws, sy, sx);
+    UFM_CHECK_LAUNCH("ufm_upsample_bilinear_nhwc");
+    return UFM_OK;
+}
+
+extern "C" int ufm_head_tail(const float* x, int P, int HW, int Cin, const float* w, const float* b, int Cout,
+                             const int32_t* kind_host, const float* a_host, const float* d_host, float* out,
+                             float* out_logits, void* stream) {
+    UFM_REQUIRE(x && w && b && out && kind_host && a_host && d_host, "ufm_head_tail: null pointer");
+    UFM_REQUIRE(Cout >= 1 && Cout <= 4 && Cin % 4 == 0 && Cin > 0 && P > 0 && HW > 0 && P % HW == 0, "ufm_head_tail: bad shape");
+    TailArgs ta;
+    for (int c = 0; c < 4; ++c) {
+        ta.kind[c] = c < Cout ? kind_host[c] : 0;
+        ta.a[c] = c < Cout ? a_host[c] : 1.f;
+        ta.d[c] = c < Cout ? d_host[c] : 0.f;
+    }
+    hipLaunchKernelGGL(head_tail_kernel, stream_grid((size_t)P), dim3(256), 0, (hipStream_t)stream, x, P, HW, Cin, w, b, Cout, ta, out, out_logits);
+    UFM_CHECK_LAUNCH("ufm_head_tail");
+    return UFM_OK;
+}
+
+static int fill_unmap(UnmapArgs& ua, const int32_t* rep0, const int32_t* src0, const int32_t* src1, int h, int w, int H0,
+                      int W0) {
+    for (int i = 0; i < 4; ++i) {
+        ua.rep0[i] = rep0[i];
+        ua.src0[i] = src0[i];
+        ua.src1[i] = src1 ? src1[i] : src0[i];
+    }
+    if (!(rep0[0] >= 0 && rep0[1] <= h && rep0[0] < rep0[1] && rep0[2] >= 0 && rep0[3] <= w && rep0[2] < rep0[3])) return -1;
+    if (!(src0[0] >= 0 && src0[1] <= H0 && src0[0] < src0[1] && src0[2] >= 0 && src0[3] <= W0 && src0[2] < src0[3])) return -1;
+    const float rw = (float)(rep0[3] - rep0[2]), rh = (float)(rep0[1] - rep0[0]);
+    ua.sscale[0] = (float)(ua.src0[3] - ua.src0[2]) / rw;
+    ua.sscale[1] = (float)(ua.src0[1] - ua.src0[0]) / rh;
+    ua.tscale[0] = (float)(ua.src1[3] - ua.src1[2]) / rw;
+    ua.tscale[1] = (float)(ua.src1[1] - ua.src1[0]) / rh;
+    for (int i = 0; i < 4; ++i) ua.cscale[i] = 1.f;
+    return 0;
+}
+
+extern "C" int ufm_unmap_flow(const float* flow, int B, int h, int w, const int32_t* rep0, const int32_t* src0,
+                              const int32_t* src1, int H0, int W0, float* out, uint8_t* valid, void* stream) {
+    UFM_REQUIRE(flow && rep0 && src0 && src1 && out, "ufm_unmap_flow: null pointer");
+    UFM_REQUIRE(B > 0 && h > 0 && w > 0 && H0 > 0 && W0 > 0, "ufm_unmap_flow: bad shape");
+    UnmapArgs ua;
+    UFM_REQUIRE(fill_unmap(ua, rep0, src0, src1, h, w, H0, W0) == 0, "ufm_unmap_flow: region outside its image");
+    hipLaunchKernelGGL(unmap_flow_kernel, stream_grid((size_t)B * H0 * W0), dim3(256), 0, (hipStream_t)stream, flow, B, h, w, ua, H0, W0, out, valid);
+    UFM_CHECK_LAUNCH("ufm_unmap_flow");
+    return UFM_OK;
+}
+
+extern "C" int ufm_unmap_channels(const float* chan, int B, int C, int h, int w, const int32_t* rep0,
+                                  const int32_t* src0, int H0, int W0, const float* chan_scale_host, float* out,
+                                  uint8_t* valid, void* stream) {
+    UFM_REQUIRE(chan && rep0 && src0 && out, "ufm_unmap_channels: null pointer");
+    UFM_REQUIRE(B > 0 && C > 0 && C <= 4 && h > 0 && w > 0 && H0 > 0 && W0 > 0, "ufm_unmap_channels: bad shape (C<=4)");
+    UnmapArgs ua;
+    UFM_REQUIRE(fill_unmap(ua, rep0, src0, nullptr, h, w, H0, W0) == 0, "ufm_unmap_channels: region outside its image");
+    if (chan_scale_host)
+        for (int c = 0; c < C; ++c) ua.cscale[c] = chan_scale_host[c];
+    hipLaunchKernelGGL(unmap_channels_kernel, stream_grid((size_t)B * H0 * W0), dim3(256), 0, (hipStream_t)stream, chan, B, C, h, w, ua, H0, W0, chan_scale_host ? 1 : 0, out, valid);
+    UFM_CHECK_LAUNCH("ufm_unmap_channels");
+    return UFM_OK;
+}
+
+extern "C" int ufm_pixel_shuffle_planar(const float* x, int B, int gh, int gw, int C, int p, float* out, void* stream) {
+    UFM_REQUIRE(x && out && B > 0 && gh > 0 && gw > 0 && C > 0 && p > 0, "ufm_pixel_shuffle_planar: bad args");
+    hipLaunchKernelGGL(pixel_shuffle_kernel, stream_grid((size_t)B * C * gh * p * gw * p), dim3(256), 0, (hipStream_t)stream, x, B, gh, gw, C, p, out);
+    UFM_CHECK_LAUNCH("ufm_pixel_shuffle_planar");
+    return UFM_OK;
+}
+
+extern "C" int ufm_cast_f32_to_bf16(const float* in, uint16_t* out, int64_t n, void* stream) {
+    UFM_REQUIRE(in && out && n > 0 && n % 4 == 0, "ufm_cast_f32_to_bf16: n must be a positive multiple of 4");
+    hipLaunchKernelGGL(cast_bf16_kernel, stream_grid((size_t)n / 4), dim3(256), 0, (hipStream_t)stream, in, out, (size_t)n / 4);
+    UFM_CHECK_LAUNCH("ufm_cast_f32_to_bf16");
+    return UFM_OK;
+}
+
+extern "C" int ufm_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    UFM_REQUIRE(a && b && out && n > 0 && n % 4 == 0, "ufm_add_f32: n must be a positive multiple of 4");
+    hipLaunchKernelGGL(add_kernel, stream_grid((size_t)n / 4), dim3(256), 0, (hipStream_t)stream, a, b, out, (size_t)n / 4);
+    UFM_CHECK_LAUNCH("ufm_add_f32");
+    return UFM_OK;
+}
+
+extern "C" int ufm_add_rows(const float* a, int lda, const float* tab, int ldtab, int tab_mod, float* out, int ldo,
+                            int out_row_group, int rows, int D, void* stream) {
+    UFM_REQUIRE(a && out && rows > 0 && D > 0 && D % 4 == 0 && lda % 4 == 0 && ldo % 4 == 0 && (!tab || ldtab % 4 == 0), "ufm_add_rows: bad args");
+    hipLaunchKernelGGL(add_rows_kernel, stream_grid((size_t)rows * (D / 4)), dim3(256), 0, (hipStream_t)stream, a, lda, tab, ldtab, tab_mod, out, ldo, out_row_group, rows, D);
+    UFM_CHECK_LAUNCH("ufm_add_rows");
+    return UFM_OK;
+}

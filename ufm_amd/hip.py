@@ -1,0 +1,184 @@
+"""ctypes binding of ``libufm_hip.so`` (C ABI declared in ``include/ufm_hip.h``).
+
+This is the whole "FFI": raw device pointers (``tensor.data_ptr()``), ints, floats and the
+current HIP stream.  PyTorch is used only to own device memory and streams.  There is NO
+fallback: if the shared library is missing or a call fails, a ``RuntimeError`` is raised.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libufm_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+
+_lib: Optional[C.CDLL] = None
+
+_vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
+_fp3 = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+
+# name -> argtypes; MUST mirror include/ufm_hip.h (tests/test_abi.py checks the symbol set)
+SIGNATURES = {
+    "ufm_patchify": [_vp, _i, _i, _i, _i, _i, _i, _fp3, _fp3, _vp, _i, _i, _vp],
+    "ufm_resize_antialias": [_vp, _i, _i, _i, _i, _i, _fp3, _fp3, _vp, _i, _i, _vp, _vp],
+    "ufm_gemm_bf16": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp],
+    "ufm_layernorm": [_vp, _i, _vp, _i, _i, _vp, _vp, _f, _vp, _i, _i, _vp],
+    "ufm_fill_rows": [_vp, _i, _i, _i, _vp, _i, _vp],
+    "ufm_add_rows": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp],
+    "ufm_attention_bf16": [_vp, _vp, _i, _i, _i, _f, _vp],
+    "ufm_attention_f32": [_vp, _vp, _i, _i, _i, _f, _vp],
+    "ufm_conv2d_nhwc_f32": [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp],
+    "ufm_upsample_bilinear_nhwc": [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp],
+    "ufm_head_tail": [_vp, _i, _i, _i, _vp, _vp, _i, _ip, _fp3, _fp3, _vp, _vp, _vp],
+    "ufm_unmap_flow": [_vp, _i, _i, _i, _ip, _ip, _ip, _i, _i, _vp, _vp, _vp],
+    "ufm_unmap_channels": [_vp, _i, _i, _i, _i, _ip, _ip, _i, _i, _fp3, _vp, _vp, _vp],
+    "ufm_refine": [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
+    "ufm_pixel_shuffle_planar": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "ufm_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
+    "ufm_add_f32": [_vp, _vp, _vp, _i64, _vp],
+}
+PLAIN = {"ufm_abi_version": (C.c_int, []), "ufm_last_error": (C.c_char_p, []), "ufm_built_arch": (C.c_char_p, [])}
+
+
+def lib() -> C.CDLL:
+    """Load the library (once).  Raises loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C ufm_amd/csrc`). "
+                "ufm_amd has no CPU / PyTorch fallback."
+            )
+        l = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        for name, (res, argtypes) in PLAIN.items():
+            fn = getattr(l, name)
+            fn.argtypes = argtypes
+            fn.restype = res
+        if l.ufm_abi_version() != 1:
+            raise RuntimeError("libufm_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def _check(rc: int, name: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (rc={rc}): {lib().ufm_last_error().decode()}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    assert t.is_cuda, "ufm_amd kernels need device tensors"
+    return t.data_ptr()
+
+
+def _f3(v: Sequence[float]):
+    return (C.c_float * len(v))(*[float(x) for x in v])
+
+
+def _i4(v: Sequence[int]):
+    return (C.c_int32 * len(v))(*[int(x) for x in v])
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(t.dtype)
+
+
+# ----------------------------------------------------------------------------- wrappers
+def patchify(img: torch.Tensor, layout: int, B: int, H: int, W: int, patch: int, scale3, shift3, out: torch.Tensor, kpad: int):
+    in_dtype = 0 if img.dtype == torch.uint8 else 1
+    assert img.is_contiguous() and out.is_contiguous()
+    _check(lib().ufm_patchify(_p(img), in_dtype, layout, B, H, W, patch, _f3(scale3), _f3(shift3), _p(out), _dt(out), kpad, _stream()), "ufm_patchify")
+
+
+def resize_antialias(img: torch.Tensor, layout: int, B: int, H: int, W: int, scale3, shift3, out: torch.Tensor, Ho: int, Wo: int, tmp: torch.Tensor):
+    in_dtype = 0 if img.dtype == torch.uint8 else 1
+    assert img.is_contiguous() and tmp.numel() >= B * 3 * H * Wo
+    _check(lib().ufm_resize_antialias(_p(img), in_dtype, layout, B, H, W, _f3(scale3), _f3(shift3), _p(out), Ho, Wo, _p(tmp), _stream()), "ufm_resize_antialias")
+
+
+def gemm_bf16(A, W, M, N, K, out, *, bias=None, act=ACT_NONE, gamma=None, res=None, ldres=0, res_row_mod=0, lda=None, ldw=None, ldo=None, out_row_group=0):
+    _check(
+        lib().ufm_gemm_bf16(_p(A), lda or K, _p(W), ldw or K, M, N, K, _p(bias), act, _p(gamma), _p(res), ldres or N, res_row_mod, _p(out), _dt(out), ldo or N, out_row_group, _stream()),
+        "ufm_gemm_bf16",
+    )
+
+
+def layernorm(x, ldx, row_index, rows_out, D, weight, bias, eps, out, ldo=None):
+    _check(lib().ufm_layernorm(_p(x), ldx, _p(row_index), rows_out, D, _p(weight), _p(bias), eps, _p(out), _dt(out), ldo or D, _stream()), "ufm_layernorm")
+
+
+def fill_rows(out, ldo, n_groups, group_stride_rows, src, D):
+    _check(lib().ufm_fill_rows(_p(out), ldo, n_groups, group_stride_rows, _p(src), D, _stream()), "ufm_fill_rows")
+
+
+def add_rows(a, lda, tab, tab_mod, out, ldo, out_row_group, rows, D, ldtab=None):
+    _check(lib().ufm_add_rows(_p(a), lda, _p(tab), ldtab or D, tab_mod, _p(out), ldo, out_row_group, rows, D, _stream()), "ufm_add_rows")
+
+
+def attention(qkv, out, B, N, H, scale):
+    if qkv.dtype == torch.bfloat16:
+        _check(lib().ufm_attention_bf16(_p(qkv), _p(out), B, N, H, scale, _stream()), "ufm_attention_bf16")
+    else:
+        _check(lib().ufm_attention_f32(_p(qkv), _p(out), B, N, H, scale, _stream()), "ufm_attention_f32")
+
+
+def conv2d(x, B, H, W, Cin, weight, Cout, KH, KW, stride, pad, out, zero_page, *, relu_in=False, bias=None, act=ACT_NONE, gamma=None, res1=None, res2=None, shuffle=0):
+    _check(
+        lib().ufm_conv2d_nhwc_f32(_p(x), B, H, W, Cin, _p(weight), Cout, KH, KW, stride, pad, int(relu_in), _p(bias), act, _p(gamma), _p(res1), _p(res2), shuffle, _p(out), 0, _p(zero_page), _stream()),
+        "ufm_conv2d_nhwc_f32",
+    )
+
+
+def upsample_bilinear(x, B, H, W, C, out, Ho, Wo, crop_h=0, crop_w=0):
+    _check(lib().ufm_upsample_bilinear_nhwc(_p(x), B, H, W, C, _p(out), Ho, Wo, crop_h, crop_w, _stream()), "ufm_upsample_bilinear_nhwc")
+
+
+def head_tail(x, P, HW, Cin, w, b, Cout, kinds, a, d, out, out_logits=None):
+    _check(lib().ufm_head_tail(_p(x), P, HW, Cin, _p(w), _p(b), Cout, _i4(kinds), _f3(a), _f3(d), _p(out), _p(out_logits), _stream()), "ufm_head_tail")
+
+
+def unmap_flow(flow, B, h, w, rep0, src0, src1, H0, W0, out, valid=None):
+    _check(lib().ufm_unmap_flow(_p(flow), B, h, w, _i4(rep0), _i4(src0), _i4(src1), H0, W0, _p(out), _p(valid), _stream()), "ufm_unmap_flow")
+
+
+def unmap_channels(chan, B, Cc, h, w, rep0, src0, H0, W0, out, valid=None, chan_scale=None):
+    cs = _f3(chan_scale) if chan_scale is not None else None
+    _check(lib().ufm_unmap_channels(_p(chan), B, Cc, h, w, _i4(rep0), _i4(src0), H0, W0, cs, _p(out), _p(valid), _stream()), "ufm_unmap_channels")
+
+
+def refine(flow, feat, B, Cc, H, W, P, temperature, bias, residual, log_softmax=None):
+    _check(lib().ufm_refine(_p(flow), _p(feat), B, Cc, H, W, P, temperature, _p(bias), _p(residual), _p(log_softmax), _stream()), "ufm_refine")
+
+
+def pixel_shuffle_planar(x, B, gh, gw, Cc, p, out):
+    _check(lib().ufm_pixel_shuffle_planar(_p(x), B, gh, gw, Cc, p, _p(out), _stream()), "ufm_pixel_shuffle_planar")
+
+
+def cast_bf16(x, out):
+    _check(lib().ufm_cast_f32_to_bf16(_p(x), _p(out), x.numel(), _stream()), "ufm_cast_f32_to_bf16")
+
+
+def add_f32(a, b, out):
+    _check(lib().ufm_add_f32(_p(a), _p(b), _p(out), a.numel(), _stream()), "ufm_add_f32")
