@@ -435,9 +435,9 @@ def ufm_tiny_config(resolution_wh: Tuple[int, int] = (56, 56), refine: bool = Fa
         enc_dim=128,
         enc_depth=3,
         enc_heads=2,
-        info_dim=64,
+        info_dim=128,
         info_depth=4,
-        info_heads=1,
+        info_heads=2,
         layer_dims=(32, 32, 64, 64),
         feature_dim=64,
         resolution_wh=resolution_wh,

@@ -1,0 +1,178 @@
+"""End-to-end parity: ufm_amd (HIP kernels through the C ABI) vs the fp32 CPU oracle on identical
+weights and inputs, plus the reference-glue goldens and size-independent properties.
+
+Tolerances (stated, measured on MI355X):
+  numerics="parity" (exact-fp32 MFMA): flow max-abs <= 1e-3 px, covisibility max-abs <= 1e-3
+                                        (north-star gate: "flow within 1e-3 max-abs of reference")
+  numerics="fast"   (bf16 MFMA trunk = the reference's own GPU autocast policy): the bf16 operand
+                    rounding (2^-9 relative) propagates through 36 blocks; bound is relative to
+                    the flow's dynamic range and written next to each assert.
+"""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def env():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import ufm_amd
+    from oracle import ufm_ref as R
+    from ufm_amd import hip
+
+    hip.lib()
+    return ufm_amd, R
+
+
+def build_pair(env, refine=False, res=(56, 56), seed=3, cfg_fn=None):
+    ufm_amd, R = env
+    cfg_o = R.ufm_tiny_config(resolution_wh=res, refine=refine) if cfg_fn is None else cfg_fn(R)
+    cfg_p = ufm_amd.ufm_tiny_config(resolution_wh=res, refine=refine) if cfg_fn is None else cfg_fn(ufm_amd)
+    oracle = R.UFMRef(**cfg_o).eval()
+    R.init_weights_(oracle, seed)
+    cls = ufm_amd.UniFlowMatchClassificationRefinement if refine else ufm_amd.UniFlowMatchConfidence
+    prod = cls(**cfg_p).eval()
+    missing = prod.load_state_dict(oracle.state_dict(), strict=True)
+    return oracle, prod.to(DEV)
+
+
+def u8(shape, seed):
+    return torch.randint(0, 256, shape, dtype=torch.uint8, generator=torch.Generator().manual_seed(seed))
+
+
+def compare(o, p):
+    fo, fp = o.flow.flow_output, p.flow.flow_output.cpu()
+    assert fo.shape == fp.shape
+    df = (fo - fp).abs().max().item()
+    dm = (o.covisibility.mask - p.covisibility.mask.cpu()).abs().max().item() if o.covisibility is not None else 0.0
+    return df, dm, fo.abs().max().item()
+
+
+@pytest.mark.parametrize("refine", [False, True])
+def test_tiny_parity_mode_identity_resolution(env, refine):
+    oracle, prod = build_pair(env, refine=refine)
+    prod.set_numerics("parity")
+    src, tgt = u8((2, 56, 56, 3), 1), u8((2, 56, 56, 3), 2)
+    o = oracle.predict_correspondences_batched(src, tgt)
+    p = prod.predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
+    df, dm, mx = compare(o, p)
+    assert df <= 1e-3 and dm <= 1e-3, (df, dm, mx)
+    assert p.covisibility.logits is None and p.covisibility.mask.shape == (2, 56, 56)
+    if refine:
+        assert p.classification_refinement is None  # un-mapped result carries flow + covisibility only (base.py:276-334)
+
+
+@pytest.mark.parametrize(
+    "src_shape,tgt_shape,layout,dtype",
+    [
+        ((2, 75, 100, 3), (2, 60, 90, 3), "bhwc", "u8"),
+        ((1, 3, 30, 40), (1, 3, 33, 47), "bchw", "f32"),
+        ((90, 70, 3), (64, 80, 3), "hwc", "u8"),
+    ],
+)
+def test_tiny_parity_mode_resized_inputs(env, src_shape, tgt_shape, layout, dtype):
+    oracle, prod = build_pair(env)
+    prod.set_numerics("parity")
+    if dtype == "u8":
+        src, tgt, norm = u8(src_shape, 5), u8(tgt_shape, 6), None
+    else:
+        g = torch.Generator().manual_seed(7)
+        src, tgt, norm = torch.randn(src_shape, generator=g), torch.randn(tgt_shape, generator=g), "dust3r"
+    o = oracle.predict_correspondences_batched(src, tgt, data_norm_type=norm)
+    p = prod.predict_correspondences_batched(src.to(DEV), tgt.to(DEV), data_norm_type=norm)
+    df, dm, mx = compare(o, p)
+    # un-mapping multiplies coordinates O(100) by ratios in fp32: allow a few ulp of those on top of 1e-3
+    assert df <= 1.5e-3 and dm <= 1e-3, (df, dm, mx)
+    assert p.flow.flow_output.shape[0] == (1 if len(src_shape) == 3 else src_shape[0])
+
+
+@pytest.mark.parametrize("name,refine", [("wiring_confidence.npz", False), ("wiring_refine.npz", True)])
+def test_against_reference_wiring_goldens(env, golden_dir, name, refine):
+    """Goldens = the REFERENCE's forward + pre/post running on the restated blocks (make_goldens.py)."""
+    ufm_amd, R = env
+    g = np.load(os.path.join(golden_dir, name))
+    _, prod = build_pair(env, refine=refine, seed=int(g["seed"]))
+    prod.set_numerics("parity")
+    p = prod.predict_correspondences_batched(torch.from_numpy(g["src"]).to(DEV), torch.from_numpy(g["tgt"]).to(DEV))
+    assert np.abs(p.flow.flow_output.cpu().numpy() - g["flow"]).max() <= 1e-3
+    assert np.abs(p.covisibility.mask.cpu().numpy() - g["mask"]).max() <= 1e-3
+    p2 = prod.predict_correspondences_batched(torch.from_numpy(g["src2"]).to(DEV), torch.from_numpy(g["tgt2"]).to(DEV))
+    assert np.abs(p2.flow.flow_output.cpu().numpy() - g["flow2"]).max() <= 1.5e-3
+    assert np.abs(p2.covisibility.mask.cpu().numpy() - g["mask2"]).max() <= 1e-3
+
+
+def test_tiny_fast_mode_tolerance(env):
+    oracle, prod = build_pair(env)
+    src, tgt = u8((2, 56, 56, 3), 1), u8((2, 56, 56, 3), 2)
+    o = oracle.predict_correspondences_batched(src, tgt)
+    p = prod.set_numerics("fast").predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
+    df, dm, mx = compare(o, p)
+    print(f"fast-mode tiny: flow max-abs {df:.4g} (range {mx:.3g}), mask max-abs {dm:.4g}")
+    assert df <= 0.05 * mx and dm <= 0.05, (df, dm, mx)  # bf16 trunk: a few % of range at random O(1) weights
+
+
+def test_forward_lower_level_api_and_errors(env):
+    ufm_amd, R = env
+    oracle, prod = build_pair(env)
+    prod.set_numerics("parity")
+    g = torch.Generator().manual_seed(0)
+    a, b = torch.randn(1, 3, 56, 56, generator=g), torch.randn(1, 3, 56, 56, generator=g)
+    o = oracle.forward(a, b)
+    v1 = {"img": a.to(DEV), "symmetrized": False, "data_norm_type": "dinov2"}
+    v2 = {"img": b.to(DEV), "symmetrized": False, "data_norm_type": "dinov2"}
+    p = prod(v1, v2)
+    assert (o.flow.flow_output - p.flow.flow_output.cpu()).abs().max() <= 1e-3
+    assert (o.covisibility.logits - p.covisibility.logits.cpu()).abs().max() <= 2e-3
+    with pytest.raises(NotImplementedError, match="Unequal"):
+        prod(v1, {"img": torch.zeros(1, 3, 56, 70, device=DEV), "symmetrized": False, "data_norm_type": "dinov2"})
+    with pytest.raises(ValueError, match="3 channels"):
+        prod.predict_correspondences_batched(torch.zeros(1, 4, 8, 8, dtype=torch.uint8, device=DEV), torch.zeros(1, 4, 8, 8, dtype=torch.uint8, device=DEV))
+    with pytest.raises(AssertionError, match="data_norm_type"):
+        prod.predict_correspondences_batched(torch.zeros(1, 3, 56, 56, device=DEV), torch.zeros(1, 3, 56, 56, device=DEV))
+    with pytest.raises(ValueError, match="float32 or torch.uint8"):
+        prod.predict_correspondences_batched(torch.zeros(1, 3, 56, 56, dtype=torch.int32, device=DEV), torch.zeros(1, 3, 56, 56, dtype=torch.int32, device=DEV))
+    with pytest.raises(RuntimeError, match="GPU only"):
+        prod.predict_correspondences_batched(torch.zeros(1, 56, 56, 3, dtype=torch.uint8), torch.zeros(1, 56, 56, 3, dtype=torch.uint8))
+
+
+def test_batch_split_equivalence_and_determinism(env):
+    """Multi-GPU correctness by construction: pairs are independent, so a batch processed whole equals
+    the same pairs processed in shards, bit for bit."""
+    _, prod = build_pair(env)
+    src, tgt = u8((4, 56, 56, 3), 1).to(DEV), u8((4, 56, 56, 3), 2).to(DEV)
+    whole = prod.predict_correspondences_batched(src, tgt).flow.flow_output.clone()
+    again = prod.predict_correspondences_batched(src, tgt).flow.flow_output.clone()
+    assert torch.equal(whole, again)
+    parts = torch.cat([prod.predict_correspondences_batched(src[i : i + 2], tgt[i : i + 2]).flow.flow_output.clone() for i in (0, 2)])
+    assert torch.equal(whole, parts)
+
+
+def test_ufm_base_full_size_parity(env):
+    """BASELINE config 2 shape (UFM-Base, 518x518) at B=1: parity mode <= 1e-3 px vs the fp32 CPU
+    oracle; fast (bf16) mode tolerance measured and bounded."""
+    ufm_amd, R = env
+    torch.manual_seed(0)
+    oracle = R.UFMRef(**R.ufm_base_config()).eval()
+    R.init_weights_(oracle, 0)
+    prod = ufm_amd.UniFlowMatchConfidence(**ufm_amd.ufm_base_config()).eval()
+    prod.load_state_dict(oracle.state_dict(), strict=True)
+    prod = prod.to(DEV)
+    src, tgt = u8((1, 518, 518, 3), 1234), u8((1, 518, 518, 3), 4321)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    o = oracle.predict_correspondences_batched(src, tgt)
+    p = prod.set_numerics("parity").predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
+    df, dm, mx = compare(o, p)
+    print(f"UFM-Base 518 parity mode: flow max-abs {df:.3g} px (range {mx:.3g}), mask {dm:.3g}")
+    assert df <= 1e-3 and dm <= 1e-3, (df, dm, mx)
+    pf = prod.set_numerics("fast").predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
+    df2, dm2, _ = compare(o, pf)
+    mean_abs = (o.flow.flow_output - pf.flow.flow_output.cpu()).abs().mean().item()
+    print(f"UFM-Base 518 fast (bf16) mode: flow max-abs {df2:.3g} mean-abs {mean_abs:.3g} (range {mx:.3g}), mask {dm2:.3g}")
+    assert df2 <= 0.05 * mx and dm2 <= 0.05, (df2, dm2, mx)

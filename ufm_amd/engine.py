@@ -1,0 +1,441 @@
+"""HIP execution engine for the UFM forward pass.
+
+Owns the packed device weights and the activation workspace and issues the C-ABI kernels of
+``libufm_hip.so`` on the current HIP stream, in the order of the reference's ``forward``
+(``uniflowmatch/models/ufm.py:562-662`` / ``:843-1009``).  Everything between "uint8 / float
+image on the device" and "flow / covisibility at network resolution" happens here; no torch
+compute op is used (torch only allocates buffers).
+
+Data layout in HBM
+  * tokens-major activations ``[rows][channels]``; encoder rows are ``(image, token)`` with the
+    2B images ordered [view-1 batch | view-2 batch] (ufm.py:308) and token 0 = cls; info-sharing
+    rows are ``(pair, view, patch)`` so one pair's 2*Np joint tokens are contiguous.
+  * fp32 residual stream; bf16 GEMM/attention operands in numerics mode "fast" (the reference's
+    own GPU policy: bf16 autocast trunk, base.py:273), fp32 everywhere in mode "parity".
+  * DPT heads run in fp32 in both modes (ufm.py:635) on NHWC maps == token rows, so no transposes.
+  * feature pyramids are gathered by the LayerNorm kernel through row-index tables (drop cls,
+    pick view 1) -- the reference's ``.float().contiguous()`` copies (ufm.py:602-630) do not exist.
+
+Numerics modes
+  "fast"   bf16 MFMA operands, fp32 accumulate, fp32 residual / LayerNorm / softmax statistics.
+  "parity" exact-fp32 MFMA for every contraction; tracks the fp32 CPU oracle to <= 1e-3 px.
+"""
+
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F  # only for the one-off pos-embed interpolation at pack time
+from torch import nn
+
+from . import hip
+from .modules import IMAGE_NORMALIZATION
+
+KPAD = 640  # 3*14*14 = 588 patch columns padded to a multiple of the GEMM K-step
+
+
+def _f32(t: torch.Tensor, dev) -> torch.Tensor:
+    return t.detach().to(device=dev, dtype=torch.float32).contiguous()
+
+
+class _Lin:
+    """Packed nn.Linear: weight in the mode's operand dtype, bias fp32."""
+
+    def __init__(self, lin: nn.Linear, dev, wdt):
+        self.n, self.k = lin.weight.shape
+        self.w = lin.weight.detach().to(device=dev, dtype=wdt).contiguous()
+        self.b = _f32(lin.bias, dev) if lin.bias is not None else None
+
+
+class _Blk:
+    def __init__(self, blk, dev, wdt):
+        self.n1w, self.n1b = _f32(blk.norm1.weight, dev), _f32(blk.norm1.bias, dev)
+        self.n2w, self.n2b = _f32(blk.norm2.weight, dev), _f32(blk.norm2.bias, dev)
+        self.qkv, self.proj = _Lin(blk.attn.qkv, dev, wdt), _Lin(blk.attn.proj, dev, wdt)
+        self.fc1, self.fc2 = _Lin(blk.mlp.fc1, dev, wdt), _Lin(blk.mlp.fc2, dev, wdt)
+        self.ls1 = _f32(blk.ls1.gamma, dev) if hasattr(blk.ls1, "gamma") else None
+        self.ls2 = _f32(blk.ls2.gamma, dev) if hasattr(blk.ls2, "gamma") else None
+
+
+class _Conv:
+    """Conv2d packed [Cout][KH][KW][Cin]; ConvTranspose2d(k == s) packed [(kh,kw,co)][Cin]."""
+
+    def __init__(self, conv: nn.Module, dev):
+        w = conv.weight.detach().to(device=dev, dtype=torch.float32)
+        self.b = _f32(conv.bias, dev) if conv.bias is not None else None
+        if isinstance(conv, nn.ConvTranspose2d):
+            cin, co, kh, kw = w.shape
+            assert kh == kw == conv.stride[0] == conv.stride[1] and conv.padding == (0, 0)
+            self.shuffle, self.cin, self.cout, self.k, self.stride, self.pad = kh, cin, kh * kw * co, 1, 1, 0
+            self.w = w.permute(2, 3, 1, 0).reshape(kh * kw * co, cin).contiguous()
+        else:
+            co, cin, kh, kw = w.shape
+            self.shuffle, self.cin, self.cout, self.k, self.stride, self.pad = 0, cin, co, kh, conv.stride[0], conv.padding[0]
+            self.w = w.permute(0, 2, 3, 1).contiguous()
+
+
+class _Head:
+    def __init__(self, head: nn.Sequential, dev):
+        feat, proc = head[0][0], head[0][1]
+        self.feature_dim, self.layer_dims = feat.feature_dim, feat.layer_dims
+        self.hooks = feat.hooks
+        self.act = [[_Conv(m, dev) for m in seq] for seq in feat.act_postprocess]
+        self.rn = [_Conv(getattr(feat.scratch, f"layer{i + 1}_rn"), dev) for i in range(4)]
+        self.fuse = []
+        for i in range(4):
+            f = getattr(feat.scratch, f"refinenet{i + 1}")
+            self.fuse.append(
+                dict(
+                    out=_Conv(f.out_conv, dev),
+                    r1=(_Conv(f.resConfUnit1.conv1, dev), _Conv(f.resConfUnit1.conv2, dev)),
+                    r2=(_Conv(f.resConfUnit2.conv1, dev), _Conv(f.resConfUnit2.conv2, dev)),
+                )
+            )
+        self.p_conv1 = _Conv(proc.conv1, dev)
+        self.p_conv2a = _Conv(proc.conv2[0], dev)
+        last = proc.conv2[2]
+        self.tail_w = _f32(last.weight.reshape(last.weight.shape[0], -1), dev)
+        self.tail_b = _f32(last.bias, dev)
+        self.tail_cout, self.tail_cin = last.weight.shape[0], last.weight.shape[1]
+        self.adaptors = list(head[1].adaptors)
+        self.kinds = [k for a in self.adaptors for k in a.kinds]
+        self.scale = [s for a in self.adaptors for s in a.scale]
+        self.shift = [s for a in self.adaptors for s in a.shift]
+
+
+class Engine:
+    def __init__(self, model: nn.Module, numerics: str = "fast"):
+        if numerics not in ("fast", "parity"):
+            raise ValueError("numerics must be 'fast' or 'parity'")
+        hip.lib()  # fail loudly right here if the extension is missing
+        self.model = model
+        self.numerics = numerics
+        self.adt = torch.bfloat16 if numerics == "fast" else torch.float32  # GEMM/attention operand dtype
+        self.dev: Optional[torch.device] = None
+        self._bufs: Dict[str, torch.Tensor] = {}
+        self._tables: Dict[Any, Any] = {}
+        self._packed_key = None
+
+    # ------------------------------------------------------------------ packing
+    def _pack(self) -> None:
+        m = self.model
+        dev = next(m.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("ufm_amd runs on an AMD GPU only: move the model with .to('cuda') (no CPU fallback exists)")
+        key = (str(dev), self.numerics, tuple(p._version for p in m.parameters()), tuple(p.data_ptr() for p in m.parameters()))
+        if key == self._packed_key:
+            return
+        self.dev = dev
+        self._tables.clear()
+        self._bufs.clear()
+        enc = m.encoder.model
+        self.P = enc.patch_size
+        self.D = enc.embed_dim
+        self.enc_heads = enc.num_heads
+        self.enc_indices = list(m.encoder.indices)
+        if self.D // self.enc_heads != 64 or m.info_sharing.dim // m.info_sharing.num_heads != 64:
+            raise NotImplementedError("attention kernels are built for head_dim 64 (DINOv2 ViT-S/B/L and the UFM info-sharing)")
+        wdt = self.adt
+        pe_w = enc.patch_embed.proj.weight.detach().reshape(self.D, -1).float()
+        assert pe_w.shape[1] == 3 * self.P * self.P <= KPAD
+        w = torch.zeros(self.D, KPAD)
+        w[:, : pe_w.shape[1]] = pe_w.cpu()
+        self.pe_w = w.to(device=dev, dtype=wdt).contiguous()
+        self.pe_b = _f32(enc.patch_embed.proj.bias, dev)
+        self.enc_blocks = [_Blk(b, dev, wdt) for b in enc.blocks]
+        self.enc_norm = (_f32(enc.norm.weight, dev), _f32(enc.norm.bias, dev))
+        info = m.info_sharing
+        self.Di, self.info_heads, self.info_indices = info.dim, info.num_heads, list(info.indices)
+        self.info_proj = _Lin(info.proj_embed, dev, wdt) if isinstance(info.proj_embed, nn.Linear) else None
+        self.info_blocks = [_Blk(b, dev, wdt) for b in info.self_attention_blocks]
+        self.info_norm = (_f32(info.norm.weight, dev), _f32(info.norm.bias, dev))
+        if info.max_num_views < 2:
+            raise ValueError("info sharing needs max_num_views >= 2")
+        self.heads = {"head1": _Head(m.head1, dev)}
+        if hasattr(m, "uncertainty_head"):
+            self.heads["uncertainty_head"] = _Head(m.uncertainty_head, dev)
+        self.refine = hasattr(m, "classification_head")
+        if self.refine:
+            ch = m.classification_head
+            self.cls_fc1 = _Lin(ch.mlp.fc1, dev, torch.float32)  # classification head runs in the fp32 island (ufm.py:921-965)
+            self.cls_fc2 = _Lin(ch.mlp.fc2, dev, torch.float32)
+            self.cls_out_dim = ch.output_dim
+            self.cls_bias = _f32(m.classification_bias, dev)
+            if getattr(m, "use_unet_feature", False):
+                raise NotImplementedError("use_unet_feature=True (UNet fine features) is not built yet")
+        self.zero = torch.zeros(256, device=dev, dtype=torch.float32)
+        for d, what in ((self.D, "encoder dim"), (self.Di, "info-sharing dim")):
+            if self.numerics == "fast" and (d % 128 != 0):
+                raise NotImplementedError(f"{what}={d}: the bf16 GEMM tiles need channel counts that are multiples of 128")
+            if d % 32 != 0:
+                raise NotImplementedError(f"{what}={d} must be a multiple of 32")
+        self._packed_key = key
+
+    # ------------------------------------------------------------------ small helpers
+    def buf(self, name: str, shape: Tuple[int, ...], dtype=torch.float32) -> torch.Tensor:
+        t = self._bufs.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(shape, device=self.dev, dtype=dtype)
+            self._bufs[name] = t
+        return t
+
+    def _pos_tables(self, H: int, W: int):
+        """cls+pos[0] row and the (Np, D) patch pos-embed for this resolution (hub DINOv2 semantics:
+        identity at the native grid, else bicubic with the +0.1 scale-factor offset).  One-off per
+        resolution; the only place torch.nn.functional is touched."""
+        key = ("pos", H, W)
+        if key not in self._tables:
+            enc = self.model.encoder.model
+            pe = enc.pos_embed.detach().float().cpu()
+            n_native = pe.shape[1] - 1
+            gh, gw = H // self.P, W // self.P
+            patch = pe[:, 1:]
+            if not (gh * gw == n_native and gh == gw):
+                mside = int(round(n_native**0.5))
+                assert mside * mside == n_native
+                off = enc.interpolate_offset
+                patch = F.interpolate(
+                    patch.reshape(1, mside, mside, -1).permute(0, 3, 1, 2),
+                    mode="bicubic", antialias=False, scale_factor=((gh + off) / mside, (gw + off) / mside),
+                )
+                assert tuple(patch.shape[-2:]) == (gh, gw)
+                patch = patch.permute(0, 2, 3, 1).reshape(1, gh * gw, -1)
+            cls0 = (enc.cls_token.detach().float().cpu()[0, 0] + pe[0, 0]).contiguous()
+            self._tables[key] = (cls0.to(self.dev), patch[0].contiguous().to(self.dev))
+        return self._tables[key]
+
+    def _index_tables(self, B: int, Np: int):
+        key = ("idx", B, Np)
+        if key not in self._tables:
+            N = Np + 1
+            p = torch.arange(Np)
+            b = torch.arange(B).view(B, 1)
+            v1 = (b * N + 1 + p).reshape(-1)  # view-1 patch rows of the encoder buffer
+            all_ = (torch.arange(2 * B).view(-1, 1) * N + 1 + p).reshape(-1)
+            v = torch.arange(2).view(1, 2, 1)
+            info = ((v * B + b.view(B, 1, 1)) * N + 1 + p.view(1, 1, Np)).reshape(-1)  # (pair, view, patch) order
+            iv1 = (b * 2 * Np + p).reshape(-1)
+            iv2 = (b * 2 * Np + Np + p).reshape(-1)
+            mk = lambda t: t.to(torch.int32).to(self.dev)  # noqa: E731
+            self._tables[key] = dict(enc_v1=mk(v1), enc_all=mk(all_), enc_info=mk(info), info_v1=mk(iv1), info_v2=mk(iv2))
+        return self._tables[key]
+
+    def _view_pe_table(self, Np: int) -> torch.Tensor:
+        key = ("vpe", Np)
+        if key not in self._tables:
+            t = self.model.info_sharing.view_pos_table.detach().float().cpu()
+            self._tables[key] = torch.cat([t[0:1].expand(Np, -1), t[1:2].expand(Np, -1)], dim=0).contiguous().to(self.dev)
+        return self._tables[key]
+
+    def linear(self, x, lin: _Lin, M: int, out, *, act=hip.ACT_NONE, gamma=None, res=None, res_row_mod=0, out_row_group=0, lda=None):
+        """out = epilogue(x @ W^T): bf16 MFMA GEMM in 'fast', exact-fp32 MFMA (conv kernel as dense GEMM) in 'parity'."""
+        if lin.w.dtype == torch.bfloat16:
+            hip.gemm_bf16(x, lin.w, M, lin.n, lin.k, out, bias=lin.b, act=act, gamma=gamma, res=res, res_row_mod=res_row_mod, out_row_group=out_row_group, lda=lda)
+        else:
+            assert res_row_mod == 0 and out_row_group == 0 and out.dtype == torch.float32
+            hip.conv2d(x, 1, 1, M, lin.k, lin.w, lin.n, 1, 1, 1, 0, out, self.zero, bias=lin.b, act=act, gamma=gamma, res1=res)
+
+    def conv(self, x, B, H, W, c: _Conv, out, *, relu_in=False, act=hip.ACT_NONE, res1=None, res2=None):
+        hip.conv2d(x, B, H, W, c.cin, c.w, c.cout, c.k, c.k, c.stride, c.pad, out, self.zero, relu_in=relu_in, bias=c.b, act=act, res1=res1, res2=res2, shuffle=c.shuffle)
+
+    # ------------------------------------------------------------------ transformer
+    def _blocks(self, blocks: List[_Blk], x, Bseq: int, N: int, D: int, heads: int, on_block):
+        M = Bseq * N
+        xn = self.buf("xn", (M, D), self.adt)
+        qkv = self.buf("qkv", (M, 3 * D), self.adt)
+        ao = self.buf("ao", (M, D), self.adt)
+        hid = self.buf("hid", (M, blocks[0].fc1.n), self.adt)
+        for i, w in enumerate(blocks):
+            hip.layernorm(x, D, None, M, D, w.n1w, w.n1b, 1e-6, xn)
+            self.linear(xn, w.qkv, M, qkv)
+            hip.attention(qkv, ao, Bseq, N, heads, 0.125)
+            self.linear(ao, w.proj, M, x, gamma=w.ls1, res=x)
+            hip.layernorm(x, D, None, M, D, w.n2w, w.n2b, 1e-6, xn)
+            self.linear(xn, w.fc1, M, hid, act=hip.ACT_GELU)
+            self.linear(hid, w.fc2, M, x, gamma=w.ls2, res=x)
+            on_block(i, x)
+
+    def _encode(self, patches, B2: int, H: int, W: int):
+        gh, gw = H // self.P, W // self.P
+        Np, D = gh * gw, self.D
+        N = Np + 1
+        cls0, pos = self._pos_tables(H, W)
+        x = self.buf("enc_x", (B2 * N, D))
+        hip.fill_rows(x, D, B2, N, cls0, D)
+        if self.numerics == "fast":
+            hip.gemm_bf16(patches, self.pe_w, B2 * Np, D, KPAD, x, bias=self.pe_b, res=pos, res_row_mod=Np, out_row_group=Np)
+        else:
+            tmp = self.buf("pe_tmp", (B2 * Np, D))
+            hip.conv2d(patches, 1, 1, B2 * Np, KPAD, self.pe_w, D, 1, 1, 1, 0, tmp, self.zero, bias=self.pe_b)
+            hip.add_rows(tmp, D, pos, Np, x, D, Np, B2 * Np, D)
+        return x, Np, N
+
+    # ------------------------------------------------------------------ DPT head
+    def _head(self, hw: _Head, tag: str, levels: List[torch.Tensor], level_dims: List[int], B: int, gh: int, gw: int, H: int, W: int):
+        Fd = hw.feature_dim
+        ld = hw.layer_dims
+        sizes = [(4 * gh, 4 * gw), (2 * gh, 2 * gw), (gh, gw), ((gh - 1) // 2 + 1, (gw - 1) // 2 + 1)]
+        r = []
+        for i in range(4):
+            lvl = levels[hw.hooks[i]]
+            t = self.buf(f"{tag}_act{i}", (B, gh, gw, ld[i]))
+            self.conv(lvl, B, gh, gw, hw.act[i][0], t)
+            u = t
+            if i < 2 or i == 3:
+                u = self.buf(f"{tag}_post{i}", (B, sizes[i][0], sizes[i][1], ld[i]))
+                self.conv(t, B, gh, gw, hw.act[i][1], u)
+            ri = self.buf(f"{tag}_rn{i}", (B, sizes[i][0], sizes[i][1], Fd))
+            self.conv(u, B, sizes[i][0], sizes[i][1], hw.rn[i], ri)
+            r.append(ri)
+
+        def rcu(x, pair, h, w, name, extra_res=None):
+            t1 = self.buf(f"{tag}_{name}_t", (B, h, w, Fd))
+            o = self.buf(f"{tag}_{name}_o", (B, h, w, Fd))
+            self.conv(x, B, h, w, pair[0], t1, relu_in=True)
+            self.conv(t1, B, h, w, pair[1], o, relu_in=True, res1=x, res2=extra_res)
+            return o
+
+        path = None
+        for lvl in (3, 2, 1, 0):
+            h, w = sizes[lvl]
+            f = hw.fuse[lvl]
+            if path is None:
+                s = r[lvl]
+            else:
+                s = rcu(r[lvl], f["r1"], h, w, f"f{lvl}a", extra_res=path)  # path + resConfUnit1(r)
+            o = rcu(s, f["r2"], h, w, f"f{lvl}b")
+            # out_conv (1x1) commutes with the bilinear x2 (weights sum to 1): run it at low resolution
+            c = self.buf(f"{tag}_f{lvl}c", (B, h, w, Fd))
+            self.conv(o, B, h, w, f["out"], c)
+            if lvl == 3:
+                th, tw = sizes[2]  # refinenet4 output is cropped to layer-3's grid
+                path = self.buf(f"{tag}_p{lvl}", (B, th, tw, Fd))
+                hip.upsample_bilinear(c, B, h, w, Fd, path, 2 * h, 2 * w, th, tw)
+            else:
+                path = self.buf(f"{tag}_p{lvl}", (B, 2 * h, 2 * w, Fd))
+                hip.upsample_bilinear(c, B, h, w, Fd, path, 2 * h, 2 * w)
+        h8, w8 = 2 * sizes[0][0], 2 * sizes[0][1]
+        c1 = self.buf(f"{tag}_pc1", (B, h8, w8, hw.p_conv1.cout))
+        self.conv(path, B, h8, w8, hw.p_conv1, c1)
+        up = self.buf(f"{tag}_up", (B, H, W, hw.p_conv1.cout))
+        hip.upsample_bilinear(c1, B, h8, w8, hw.p_conv1.cout, up, H, W)
+        c2 = self.buf(f"{tag}_pc2", (B, H, W, hw.p_conv2a.cout))
+        self.conv(up, B, H, W, hw.p_conv2a, c2, act=hip.ACT_RELU)
+        out = torch.empty((B, hw.tail_cout, H, W), device=self.dev, dtype=torch.float32)
+        logits = torch.empty_like(out) if 1 in hw.kinds else None
+        hip.head_tail(c2, B * H * W, H * W, hw.tail_cin, hw.tail_w, hw.tail_b, hw.tail_cout, hw.kinds, hw.scale, hw.shift, out, logits)
+        res, c0 = {}, 0
+        for a in hw.adaptors:
+            n = a.required_channels
+            res[a.name] = dict(value=out[:, c0 : c0 + n], logits=logits[:, c0 : c0 + n] if logits is not None else None, kind=a.cls_name)
+            c0 += n
+        return res
+
+    # ------------------------------------------------------------------ full forward
+    @torch.no_grad()
+    def forward(self, src, tgt, *, layout: int, scale3, shift3, H: int, W: int, Hs: int, Ws: int, Ht: int, Wt: int) -> Dict[str, Any]:
+        """src/tgt: device images (uint8 or float32, BHWC layout=0 / BCHW layout=1) of sizes
+        (Hs,Ws)/(Ht,Wt); (H,W) is the network resolution.  Returns network-resolution outputs."""
+        self._pack()
+        B = src.shape[0]
+        B2 = 2 * B
+        gh, gw = H // self.P, W // self.P
+        Np = gh * gw
+        patches = self.buf("patches", (B2 * Np, KPAD), self.adt)
+        for v, (img, h0, w0) in enumerate(((src, Hs, Ws), (tgt, Ht, Wt))):
+            dst = patches[v * B * Np : (v + 1) * B * Np]
+            if (h0, w0) == (H, W):
+                hip.patchify(img, layout, B, H, W, self.P, scale3, shift3, dst, KPAD)
+            else:  # normalise-on-load + separable antialias resize (flow_resizing.py:313-326), then patchify
+                rs = self.buf(f"resized{v}", (B, 3, H, W))
+                tmp = self.buf(f"resize_tmp{v}", (B * 3 * h0 * W,))
+                hip.resize_antialias(img, layout, B, h0, w0, scale3, shift3, rs, H, W, tmp)
+                hip.patchify(rs, 1, B, H, W, self.P, [1.0, 1.0, 1.0], [0.0, 0.0, 0.0], dst, KPAD)
+        return self._forward_patches(patches, B, H, W)
+
+    def _forward_patches(self, patches, B: int, H: int, W: int) -> Dict[str, Any]:
+        B2 = 2 * B
+        gh, gw = H // self.P, W // self.P
+        x, Np, N = self._encode(patches, B2, H, W)
+        idx = self._index_tables(B, Np)
+        D, Di = self.D, self.Di
+        nw, nb = self.enc_norm
+        enc_first = None
+        last_i = len(self.enc_blocks) - 1
+        lvl0 = self.buf("lvl0", (B * Np, D))
+        enc_info = self.buf("enc_info", (B * 2 * Np, D), self.adt)
+
+        def on_enc(i, xx):
+            nonlocal enc_first
+            if self.refine and i == self.enc_indices[0]:
+                enc_first = self.buf("enc_first", (B2 * Np, D))
+                hip.layernorm(xx, D, idx["enc_all"], B2 * Np, D, nw, nb, 1e-6, enc_first)
+            if i == self.enc_indices[-1]:
+                hip.layernorm(xx, D, idx["enc_info"], B * 2 * Np, D, nw, nb, 1e-6, enc_info)
+                hip.layernorm(xx, D, idx["enc_v1"], B * Np, D, nw, nb, 1e-6, lvl0)
+
+        blocks = self.enc_blocks[: self.enc_indices[-1] + 1]  # blocks past the last returned index never matter
+        self._blocks(blocks, x, B2, N, D, self.enc_heads, on_enc)
+
+        # ---- info sharing: joint attention over the 2*Np tokens of each pair ----
+        M2 = B * 2 * Np
+        y = self.buf("info_x", (M2, Di))
+        vpe = self._view_pe_table(Np)
+        if self.info_proj is None:
+            src32 = enc_info if enc_info.dtype == torch.float32 else None
+            if src32 is None:
+                src32 = self.buf("enc_info32", (M2, D))
+                hip.layernorm(x, D, idx["enc_info"], M2, D, nw, nb, 1e-6, src32)
+            hip.add_rows(src32, D, vpe, 2 * Np, y, Di, 0, M2, Di)
+        elif self.numerics == "fast":
+            hip.gemm_bf16(enc_info, self.info_proj.w, M2, Di, D, y, bias=self.info_proj.b, res=vpe, res_row_mod=2 * Np)
+        else:
+            tmp = self.buf("info_tmp", (M2, Di))
+            self.linear(enc_info, self.info_proj, M2, tmp)
+            hip.add_rows(tmp, Di, vpe, 2 * Np, y, Di, 0, M2, Di)
+        inw, inb = self.info_norm
+        inter: List[torch.Tensor] = []
+
+        def on_info(i, yy):
+            if i in self.info_indices:
+                t = self.buf(f"lvl_i{len(inter)}", (B * Np, Di))
+                hip.layernorm(yy, Di, idx["info_v1"], B * Np, Di, inw, inb, 1e-6, t)
+                inter.append(t)
+
+        self._blocks(self.info_blocks, y, B, 2 * Np, Di, self.info_heads, on_info)
+        if len(inter) != 2:
+            raise ValueError("info_sharing.indices must name two blocks (ufm.py:605-606 reads intermediates [0] and [1])")
+        lvl3 = self.buf("lvl3", (B * Np, Di))
+        hip.layernorm(y, Di, idx["info_v1"], B * Np, Di, inw, inb, 1e-6, lvl3)
+        levels = [lvl0, inter[0], inter[1], lvl3]  # ufm.py:603-608 (view-1 pyramid only; view 2's is never decoded)
+        dims = [D, Di, Di, Di]
+
+        out: Dict[str, Any] = {}
+        for tag, hw in self.heads.items():
+            out[tag] = self._head(hw, tag, levels, dims, B, gh, gw, H, W)
+
+        if self.refine:  # ufm.py:949-1007
+            lvl3b = self.buf("lvl3_v2", (B * Np, Di))
+            hip.layernorm(y, Di, idx["info_v2"], B * Np, Di, inw, inb, 1e-6, lvl3b)
+            C1 = D + Di
+            cat = self.buf("cls_in", (B2 * Np, C1))
+            # torch.cat along channels == strided row copies: enc_first | info_final, views stacked on batch
+            hip.add_rows(enc_first, D, None, 0, cat, C1, 0, B2 * Np, D)
+            hip.add_rows(lvl3, Di, None, 0, cat[:, D:], C1, 0, B * Np, Di)
+            hip.add_rows(lvl3b, Di, None, 0, cat[B * Np :, D:], C1, 0, B * Np, Di)
+            hidden = self.buf("cls_hid", (B2 * Np, self.cls_fc1.n))
+            self.linear(cat, self.cls_fc1, B2 * Np, hidden, act=hip.ACT_GELU)
+            tok = self.buf("cls_tok", (B2 * Np, self.cls_fc2.n))
+            self.linear(hidden, self.cls_fc2, B2 * Np, tok)
+            feats = torch.empty((B2, self.cls_out_dim, H, W), device=self.dev)
+            hip.pixel_shuffle_planar(tok, B2, gh, gw, self.cls_out_dim, self.P, feats)
+            flow = out["head1"]["flow"]["value"]
+            residual = torch.empty_like(flow)
+            m = self.model
+            logp = torch.empty((B, H, W, m.refinement_range, m.refinement_range), device=self.dev)
+            hip.refine(flow.contiguous(), feats, B, self.cls_out_dim, H, W, m.refinement_range, float(m.temperature), self.cls_bias, residual, logp)
+            refined = torch.empty_like(flow)
+            hip.add_f32(flow.contiguous(), residual, refined)
+            out["refine"] = dict(flow=refined, residual=residual, log_softmax=logp, feats=feats)
+        return out
