@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Headline benchmark: image-pairs/sec + p50 latency, UFM-Base 518x518, N x MI355X (BASELINE.json).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one ``predict_correspondences_batched`` over ``--batch`` (default 8) synthetic
+518x518 uint8 pairs per GPU (BASELINE config 2: "UFM-Base, random-init weights, batch=8
+518x518 synthetic pairs"), inputs resident in HBM before the timed region.  N > 1 = batch-split
+data parallel (independent pairs, weak scaling, no data-path collective; a single RCCL all_gather
+of the packed [flow|covisibility] results closes every step).
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline      dominant MFMA kernel family (by measured time) of the step: algorithmic FLOPs
+                per launch / average launch duration (HIP events on the launch stream), vs the
+                dense MFMA peak for its operand dtype; plus `attention` (the north star's
+                "attention-GEMM roofline") and per-family breakdown under `kernels`.
+  cpu_baseline  the fp32 CPU oracle (a port; the reference's own CPU path cannot run, its
+                arithmetic lives in an absent package) timed on this box's host cores on a
+                bounded sample (rank 0, N=1 only).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip table)
+PEAK_F32_TFLOPS = 157.3    # f32-input MFMA
+PEAK_HBM_GBS = 8000.0
+
+
+def host_cores() -> int:
+    """Threads the CPU baseline may use: the cgroup CPU quota if one is set, else the affinity mask,
+    capped at 16 (a 1-GPU box's CPU share; os.cpu_count() reports the whole 256-thread host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="pairs per GPU per step")
+    ap.add_argument("--res", type=int, default=518)
+    ap.add_argument("--numerics", default="fast", choices=["fast", "parity"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+
+    import ufm_amd
+    from ufm_amd import hip
+    from ufm_amd.modules import init_weights_
+
+    hip.lib()
+    res = args.res
+    cfg = ufm_amd.ufm_base_config(resolution_wh=(res, res))
+    model = ufm_amd.UniFlowMatchConfidence(**cfg).eval()
+    init_weights_(model, seed=0)  # deterministic CPU RNG: identical weights on every rank
+    model = model.to(dev).set_numerics(args.numerics)
+
+    B = args.batch
+    g = torch.Generator().manual_seed(1234 + rank)  # each rank owns its own slice of the global batch
+    src = torch.randint(0, 256, (B, res, res, 3), dtype=torch.uint8, generator=g).to(dev)
+    tgt = torch.randint(0, 256, (B, res, res, 3), dtype=torch.uint8, generator=g).to(dev)
+    gathered = torch.empty((world * B, 3, res, res), device=dev) if world > 1 else None
+    packed = torch.empty((B, 3, res, res), device=dev) if world > 1 else None
+
+    def step():
+        out = model.predict_correspondences_batched(src, tgt)
+        if world > 1:  # the trivial result gather: ONE collective per step on the packed buffer
+            packed[:, :2].copy_(out.flow.flow_output)
+            packed[:, 2].copy_(out.covisibility.mask)
+            dist.all_gather_into_tensor(gathered, packed)
+        return out
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(args.steps):
+        step()
+        ev[i + 1].record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    step_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps))
+    p50 = step_ms[len(step_ms) // 2]
+
+    line = {
+        "metric": "image-pairs/sec, UFM-Base 518x518",
+        "value": world * B * args.steps / elapsed,
+        "unit": "pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "p50_latency_ms": p50,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16" if args.numerics == "fast" else "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"UFM-Base (DINOv2 ViT-L/14 + 12x768 joint-attention + 2 DPT heads), random-init weights, "
+                        f"batch={B} {res}x{res} synthetic uint8 pairs per GPU, predict_correspondences_batched end to end",
+            "pairs_per_gpu": B,
+            "global_batch": world * B,
+            "resolution": res,
+            "numerics": f"{args.numerics}: " + ("bf16 MFMA trunk (fp32 accumulate/residual/LN/softmax stats), fp32-MFMA DPT heads" if args.numerics == "fast" else "fp32 MFMA everywhere"),
+            "parallelism": f"dp{world} (pair-batch split, RCCL all_gather of results)",
+        },
+    }
+
+    # ---- per-kernel durations: one extra instrumented step, HIP events on the launch stream ----
+    if rank == 0 and not args.no_kernel_timing:
+        hip.TIMER = hip.KernelTimer()
+        model.predict_correspondences_batched(src, tgt)
+        summ = hip.TIMER.summary()
+        hip.TIMER = None
+        kernels = {}
+        for name, d in summ.items():
+            work = sum(m for m in d["metas"] if m)
+            entry = {"launches": d["launches"], "ms_per_step": d["ms"], "avg_launch_us": 1e3 * d["ms"] / d["launches"]}
+            if name in ("ufm_gemm_bf16", "ufm_attention_bf16", "ufm_conv2d_nhwc_f32"):
+                peak = PEAK_F32_TFLOPS if name == "ufm_conv2d_nhwc_f32" or args.numerics == "parity" else PEAK_BF16_TFLOPS
+                entry.update(bound="mfma", algorithmic_gflop=work / 1e9, achieved=work / (d["ms"] * 1e-3) / 1e12, peak=peak, unit="TFLOP/s")
+                entry["frac"] = entry["achieved"] / peak
+            elif work:
+                entry.update(bound="hbm", algorithmic_gb=work / 1e9, achieved=work / (d["ms"] * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s")
+                entry["frac"] = entry["achieved"] / PEAK_HBM_GBS
+            kernels[name] = entry
+        mf = {k: v for k, v in kernels.items() if v.get("bound") == "mfma"}
+        dom = max(mf, key=lambda k: mf[k]["ms_per_step"])
+        d = mf[dom]
+        line["roofline"] = {
+            "kernel": dom, "bound": "mfma", "achieved": d["achieved"], "peak": d["peak"], "unit": "TFLOP/s", "frac": d["frac"],
+            "traffic": None, "avg_launch_us": d["avg_launch_us"], "algorithmic_gflop_per_launch": d["algorithmic_gflop"] / d["launches"],
+        }
+        if "ufm_attention_bf16" in kernels:
+            a = kernels["ufm_attention_bf16"]
+            line["attention"] = {"achieved": a["achieved"], "peak": a["peak"], "unit": "TFLOP/s", "frac": a["frac"], "ms_per_step": a["ms_per_step"]}
+        line["kernels"] = kernels
+        line["instrumented_step_ms"] = sum(v["ms_per_step"] for v in kernels.values())
+
+    # ---- CPU baseline: the oracle on this box's host cores, bounded sample ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import ufm_ref as R
+
+        ncores = host_cores()
+        torch.set_num_threads(ncores)
+        oracle = R.UFMRef(**R.ufm_base_config(resolution_wh=(res, res))).eval()
+        oracle.load_state_dict(model.state_dict(), strict=True)
+        s1, t1 = src[:1].cpu(), tgt[:1].cpu()
+        tiny = R.UFMRef(**R.ufm_tiny_config()).eval()  # page torch's CPU kernels in, outside the timing
+        tiny.predict_correspondences_batched(torch.zeros(1, 56, 56, 3, dtype=torch.uint8), torch.zeros(1, 56, 56, 3, dtype=torch.uint8))
+        c0 = time.perf_counter()
+        ref = oracle.predict_correspondences_batched(s1, t1)
+        cpu_s = time.perf_counter() - c0
+        got = model.predict_correspondences_batched(src[:1], tgt[:1])
+        line["cpu_baseline"] = {
+            "value": 1.0 / cpu_s, "unit": "pairs/s", "cores": ncores, "kind": "port",
+            "sample": f"1 pair of the same workload ({res}x{res}, same weights), fp32 eager-PyTorch oracle, {cpu_s:.1f} s",
+        }
+        line["check_vs_oracle"] = {
+            "flow_max_abs": float((got.flow.flow_output.cpu() - ref.flow.flow_output).abs().max()),
+            "flow_range": float(ref.flow.flow_output.abs().max()),
+            "covis_max_abs": float((got.covisibility.mask.cpu() - ref.covisibility.mask).abs().max()),
+        }
+
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,88 @@
+"""CPU-only checks of the C-ABI boundary: the shared library loads, exports exactly the symbols
+include/ufm_hip.h declares, the ctypes table mirrors the header, and argument validation works
+without launching anything (no GPU needed)."""
+
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(REPO, "include", "ufm_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+
+    so = os.path.join(REPO, "ufm_amd", "libufm_hip.so")
+    if not os.path.exists(so):
+        g.build()
+    from ufm_amd import hip
+
+    return hip.lib()
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ufm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound(lib):
+    from ufm_amd import hip
+
+    decl = declared_symbols()
+    assert len(decl) >= 20
+    for name in decl:
+        assert hasattr(lib, name), f"{name} declared in include/ufm_hip.h but not exported by libufm_hip.so"
+    bound = set(hip.SIGNATURES) | set(hip.PLAIN)
+    assert bound == set(decl), f"ctypes table and header disagree: {bound ^ set(decl)}"
+    exported = subprocess.run(["nm", "-D", hip.LIB_PATH], capture_output=True, text=True).stdout
+    exported = sorted(set(re.findall(r" T (ufm_[a-z0-9_]+)", exported)))
+    assert exported == decl, f"library exports {set(exported) ^ set(decl)} beyond / short of the header"
+
+
+def test_header_arg_counts_match_ctypes(lib):
+    from ufm_amd import hip
+
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for name, argtypes in hip.SIGNATURES.items():
+        m = re.search(r"\b" + name + r"\s*\((.*?)\);", text, flags=re.S)
+        assert m, name
+        nargs = len([a for a in m.group(1).split(",") if a.strip()])
+        assert nargs == len(argtypes), f"{name}: header has {nargs} parameters, ctypes table {len(argtypes)}"
+
+
+def test_version_arch_and_argument_validation(lib):
+    assert lib.ufm_abi_version() == 1
+    assert lib.ufm_built_arch() == b"gfx950"
+    # contract violations are rejected on the host before any launch (works without a GPU)
+    rc = lib.ufm_gemm_bf16(ctypes.c_void_p(16), 96, ctypes.c_void_p(16), 96, 4, 128, 96, None, 0, None, None, 0, 0, ctypes.c_void_p(16), 0, 128, 0, None)
+    assert rc == -1 and b"multiple of 64" in lib.ufm_last_error()
+    rc = lib.ufm_attention_bf16(None, None, 1, 1, 1, 0.125, None)
+    assert rc == -1 and b"null pointer" in lib.ufm_last_error()
+    rc = lib.ufm_conv2d_nhwc_f32(ctypes.c_void_p(16), 1, 4, 4, 24, ctypes.c_void_p(16), 32, 3, 3, 1, 1, 0, None, 0, None, None, None, 0, ctypes.c_void_p(16), 0, ctypes.c_void_p(16), None)
+    assert rc == -1 and b"Cin=24" in lib.ufm_last_error()
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under ufm_amd/ (or the uniflowmatch alias) may touch it."""
+    for root in ("ufm_amd", "uniflowmatch"):
+        for dirpath, _, files in os.walk(os.path.join(REPO, root)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h", ".cpp")):
+                    src = open(os.path.join(dirpath, f)).read()
+                    assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{dirpath}/{f} imports the oracle"
+                    assert "from .. import oracle" not in src
+
+
+def test_missing_extension_fails_loudly(monkeypatch, tmp_path):
+    from ufm_amd import hip
+
+    monkeypatch.setattr(hip, "_lib", None)
+    monkeypatch.setattr(hip, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU / PyTorch fallback"):
+        hip.lib()

@@ -73,9 +73,50 @@ def lib() -> C.CDLL:
     return _lib
 
 
+class KernelTimer:
+    """Optional HIP-event bracket around every C-ABI launch (bench.py's per-kernel durations).
+    Events are recorded on the stream the kernels are launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = []  # (name, start_event, end_event, meta)
+        self._open = None
+
+    def begin(self, name: str, meta=None):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self._open = (name, e0, meta)
+
+    def end(self):
+        name, e0, meta = self._open
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.records.append((name, e0, e1, meta))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1, meta in self.records:
+            d = out.setdefault(name, dict(ms=0.0, launches=0, metas=[]))
+            d["ms"] += e0.elapsed_time(e1)
+            d["launches"] += 1
+            d["metas"].append(meta)
+        return out
+
+
+TIMER: Optional[KernelTimer] = None
+
+
 def _check(rc: int, name: str) -> None:
+    if TIMER is not None and TIMER._open is not None and TIMER._open[0] == name:
+        TIMER.end()
+        TIMER._open = None
     if rc != 0:
         raise RuntimeError(f"{name} failed (rc={rc}): {lib().ufm_last_error().decode()}")
+
+
+def _t(name: str, meta=None) -> None:
+    if TIMER is not None:
+        TIMER.begin(name, meta)
 
 
 def _stream() -> int:
@@ -119,6 +160,7 @@ def resize_antialias(img: torch.Tensor, layout: int, B: int, H: int, W: int, sca
 
 
 def gemm_bf16(A, W, M, N, K, out, *, bias=None, act=ACT_NONE, gamma=None, res=None, ldres=0, res_row_mod=0, lda=None, ldw=None, ldo=None, out_row_group=0):
+    _t("ufm_gemm_bf16", 2.0 * M * N * K)
     _check(
         lib().ufm_gemm_bf16(_p(A), lda or K, _p(W), ldw or K, M, N, K, _p(bias), act, _p(gamma), _p(res), ldres or N, res_row_mod, _p(out), _dt(out), ldo or N, out_row_group, _stream()),
         "ufm_gemm_bf16",
@@ -126,6 +168,7 @@ def gemm_bf16(A, W, M, N, K, out, *, bias=None, act=ACT_NONE, gamma=None, res=No
 
 
 def layernorm(x, ldx, row_index, rows_out, D, weight, bias, eps, out, ldo=None):
+    _t("ufm_layernorm", rows_out * D * (4.0 + out.element_size()))
     _check(lib().ufm_layernorm(_p(x), ldx, _p(row_index), rows_out, D, _p(weight), _p(bias), eps, _p(out), _dt(out), ldo or D, _stream()), "ufm_layernorm")
 
 
@@ -139,12 +182,15 @@ def add_rows(a, lda, tab, tab_mod, out, ldo, out_row_group, rows, D, ldtab=None)
 
 def attention(qkv, out, B, N, H, scale):
     if qkv.dtype == torch.bfloat16:
+        _t("ufm_attention_bf16", 4.0 * B * H * N * N * 64)
         _check(lib().ufm_attention_bf16(_p(qkv), _p(out), B, N, H, scale, _stream()), "ufm_attention_bf16")
     else:
         _check(lib().ufm_attention_f32(_p(qkv), _p(out), B, N, H, scale, _stream()), "ufm_attention_f32")
 
 
 def conv2d(x, B, H, W, Cin, weight, Cout, KH, KW, stride, pad, out, zero_page, *, relu_in=False, bias=None, act=ACT_NONE, gamma=None, res1=None, res2=None, shuffle=0):
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    _t("ufm_conv2d_nhwc_f32", 2.0 * B * Ho * Wo * Cout * KH * KW * Cin)
     _check(
         lib().ufm_conv2d_nhwc_f32(_p(x), B, H, W, Cin, _p(weight), Cout, KH, KW, stride, pad, int(relu_in), _p(bias), act, _p(gamma), _p(res1), _p(res2), shuffle, _p(out), 0, _p(zero_page), _stream()),
         "ufm_conv2d_nhwc_f32",
@@ -152,6 +198,7 @@ def conv2d(x, B, H, W, Cin, weight, Cout, KH, KW, stride, pad, out, zero_page, *
 
 
 def upsample_bilinear(x, B, H, W, C, out, Ho, Wo, crop_h=0, crop_w=0):
+    _t("ufm_upsample_bilinear_nhwc", 4.0 * B * C * (H * W + (crop_h or Ho) * (crop_w or Wo)))
     _check(lib().ufm_upsample_bilinear_nhwc(_p(x), B, H, W, C, _p(out), Ho, Wo, crop_h, crop_w, _stream()), "ufm_upsample_bilinear_nhwc")
 
 
