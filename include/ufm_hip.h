@@ -43,6 +43,9 @@ const char* ufm_built_arch(void);
 /* ---- data types for out_dtype / in_dtype arguments ---- */
 #define UFM_F32 0
 #define UFM_BF16 1
+/* "split" fp32-class format: two bf16 planes [2][rows][C]; plane 0 = hi = bf16(x), plane 1 = lo =
+ * bf16(x - hi); the pointer addresses plane 0 and plane 1 follows at rows*C elements. */
+#define UFM_BF16X2 2
 
 /* ---- activation codes ---- */
 #define UFM_ACT_NONE 0
@@ -96,6 +99,7 @@ int ufm_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M,
  * Output row i is computed from input row (row_index ? row_index[i] : i): this is how the cls
  * token is dropped and views are re-ordered (models/ufm.py:313, :596-615) without a copy.
  * ===================================================================================== */
+/* out_dtype: UFM_F32, UFM_BF16 or UFM_BF16X2 (lo plane at out + rows_out*ldo elements). */
 int ufm_layernorm(const float* x, int ldx, const int32_t* row_index, int rows_out, int D,
                   const float* weight, const float* bias, float eps, void* out, int out_dtype,
                   int ldo, void* stream);
@@ -144,19 +148,31 @@ int ufm_conv2d_nhwc_f32(const float* in, int B, int H, int W, int Cin, const flo
                         const float* res2, int shuffle, float* out, int out_dtype_unused,
                         const float* zero_page /* >=128 B of zeros */, void* stream);
 
+/* Same convolution with fp32-class accuracy on the bf16 matrix cores (numerics mode "fast"): in /
+ * weight / res / out are in the UFM_BF16X2 split format and every product is evaluated as
+ * hi*hi + hi*lo + lo*hi (3 bf16 MFMAs, fp32 accumulate; ~2^-17 relative error per dot product --
+ * tighter than the TF32 cuDNN applies to the reference's fp32 island on NVIDIA by default).
+ * weight: [2][Cout][KH][KW][Cin] pre-split at pack time.  Same fused epilogue minus gamma. */
+int ufm_conv2d_nhwc_bf16x3(const uint16_t* in, int B, int H, int W, int Cin, const uint16_t* weight,
+                           int Cout, int KH, int KW, int stride, int pad, int relu_in,
+                           const float* bias, int act, const uint16_t* res1, const uint16_t* res2,
+                           int shuffle, uint16_t* out, const uint16_t* zero_page, void* stream);
+
 /* Bilinear resize, align_corners=True, NHWC fp32 ([U] FeatureFusionBlock x2 upsample,
  * DPTRegressionProcessor interpolate-to-target).  src = dst*(in-1)/(out-1).  crop_h/crop_w > 0:
  * only the top-left crop_h x crop_w of the (Ho, Wo) result is computed and stored (densely) --
  * the `[:, :, :h, :w]` slice after refinenet4 in the DPT head. */
-int ufm_upsample_bilinear_nhwc(const float* in, int B, int H, int W, int C, float* out, int Ho,
-                               int Wo, int crop_h, int crop_w, void* stream);
+int ufm_upsample_bilinear_nhwc(const void* in, int dtype /* UFM_F32 | UFM_BF16X2, in and out */, int B,
+                               int H, int W, int C, void* out, int Ho, int Wo, int crop_h, int crop_w,
+                               void* stream);
 
 /* Head tail: per pixel, y[c] = w[c,:] . x[:] + b[c] over Cin<=64 channels, then the adaptor
  * ([U] DPTRegressionProcessor.conv2[2] + FlowAdaptor / MaskAdaptor; call sites
  * models/ufm.py:644-660).  kind[c]: 0 = affine y*a[c]+d[c] (FlowAdaptor), 1 = sigmoid
  * (MaskAdaptor: writes mask to out, logits to out_logits if non-NULL).
  * x: fp32 [P][Cin] -> out: fp32 planar [B][Cout][HW] (P = B*HW). Cout <= 4. */
-int ufm_head_tail(const float* x, int P, int HW, int Cin, const float* w, const float* b, int Cout,
+int ufm_head_tail(const void* x, int in_dtype /* UFM_F32 | UFM_BF16X2 */, int P, int HW, int Cin,
+                  const float* w, const float* b, int Cout,
                   const int32_t* kind_host, const float* a_host, const float* d_host, float* out,
                   float* out_logits, void* stream);
 

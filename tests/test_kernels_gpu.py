@@ -322,3 +322,81 @@ def test_pixel_shuffle_and_misc(hip):
     fr = torch.zeros(10, D, device=DEV)
     hip.fill_rows(fr, D, 2, 5, tab[0].contiguous().to(DEV), D)
     assert torch.equal(fr.cpu()[0], tab[0]) and torch.equal(fr.cpu()[5], tab[0]) and fr.cpu()[1:5].abs().sum() == 0
+
+
+# ----------------------------------------------------------------------------- bf16x3 split-precision path
+def split(x):
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return torch.stack([hi, lo], 0).contiguous()
+
+
+def unsplit(s):
+    return s[0].float() + s[1].float()
+
+
+@pytest.mark.parametrize(
+    "B,H,W,Cin,Cout,k,stride,pad,relu_in,act,nres",
+    [
+        (2, 9, 11, 32, 32, 3, 1, 1, False, 0, 0),
+        (1, 37, 37, 64, 128, 3, 1, 1, True, 0, 2),
+        (2, 37, 37, 96, 64, 3, 2, 1, False, 0, 0),
+        (1, 20, 13, 128, 96, 1, 1, 0, False, 2, 1),
+        (1, 30, 30, 256, 256, 3, 1, 1, True, 0, 1),
+    ],
+)
+def test_conv2d_bf16x3(hip, B, H, W, Cin, Cout, k, stride, pad, relu_in, act, nres):
+    x = rnd(B, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5)
+    b = rnd(Cout, seed=3, scale=0.1)
+    ref = F.conv2d((F.relu(x) if relu_in else x).double(), w.double(), b.double(), stride=stride, padding=pad)
+    if act == 2:
+        ref = F.relu(ref)
+    res = [rnd(*ref.shape, seed=10 + i) for i in range(nres)]
+    for r in res:
+        ref = ref + r.double()
+    Ho, Wo = ref.shape[2:]
+    out = torch.zeros(2, B, Ho, Wo, Cout, device=DEV, dtype=torch.bfloat16)
+    zero = torch.zeros(256, device=DEV)
+    resd = [split(nhwc(r)).to(DEV) for r in res] + [None, None]
+    hip.conv2d_x3(split(nhwc(x)).to(DEV), B, H, W, Cin, split(w.permute(0, 2, 3, 1).contiguous()).to(DEV), Cout, k, k, stride, pad, out, zero,
+                  relu_in=relu_in, bias=b.to(DEV), act=act, res1=resd[0], res2=resd[1])
+    got = unsplit(out.cpu()).permute(0, 3, 1, 2).double()
+    err = (got - ref).abs().max().item()
+    # split inputs carry 2^-17 relative error, the dropped lo*lo term 2^-16 per product, the split store 2^-17
+    assert err <= 4e-5 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("s,Cin,Co", [(4, 32, 32), (2, 64, 48)])
+def test_conv_transpose_bf16x3(hip, s, Cin, Co):
+    B, H, W = 2, 5, 7
+    x = rnd(B, Cin, H, W, seed=1)
+    wt = rnd(Cin, Co, s, s, seed=2, scale=Cin**-0.5)
+    b = rnd(Co, seed=3, scale=0.1)
+    ref = F.conv_transpose2d(x, wt, b, stride=s)
+    wp = wt.permute(2, 3, 1, 0).reshape(s * s * Co, Cin).contiguous()
+    out = torch.zeros(2, B, H * s, W * s, Co, device=DEV, dtype=torch.bfloat16)
+    hip.conv2d_x3(split(nhwc(x)).to(DEV), B, H, W, Cin, split(wp).to(DEV), s * s * Co, 1, 1, 1, 0, out, torch.zeros(256, device=DEV), bias=b.to(DEV), shuffle=s)
+    assert (unsplit(out.cpu()).permute(0, 3, 1, 2) - ref).abs().max().item() <= 4e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_split_format_layernorm_upsample_tail(hip):
+    rows, D = 37, 128
+    x = rnd(rows, D, seed=1, scale=3.0)
+    w, b = 1 + rnd(D, seed=2, scale=0.1), rnd(D, seed=3, scale=0.1)
+    ref = F.layer_norm(x, (D,), w, b, 1e-6)
+    out = torch.zeros(2, rows, D, device=DEV, dtype=torch.bfloat16)
+    hip.layernorm(x.to(DEV), D, None, rows, D, w.to(DEV), b.to(DEV), 1e-6, out, split=True)
+    assert (unsplit(out.cpu()) - ref).abs().max().item() <= 4e-5  # 2^-17 relative of |y| <~ 4
+    B, H, W, Cc = 2, 7, 9, 8
+    xi = rnd(B, Cc, H, W, seed=4)
+    refu = F.interpolate(xi, size=(14, 18), mode="bilinear", align_corners=True)[:, :, :13, :17]
+    ou = torch.zeros(2, B, 13, 17, Cc, device=DEV, dtype=torch.bfloat16)
+    hip.upsample_bilinear(split(nhwc(xi)).to(DEV), B, H, W, Cc, ou, 14, 18, 13, 17)
+    assert (unsplit(ou.cpu()).permute(0, 3, 1, 2) - refu).abs().max().item() <= 6e-5
+    HW, Cin = 35, 32
+    xt, wt_, bt = rnd(B * HW, Cin, seed=1), rnd(2, Cin, seed=2), rnd(2, seed=3)
+    y = (xt @ wt_.T + bt).reshape(B, HW, 2).permute(0, 2, 1)
+    ot = torch.zeros(B, 2, HW, device=DEV)
+    hip.head_tail(split(xt).to(DEV), B * HW, HW, Cin, wt_.to(DEV), bt.to(DEV), 2, [0, 1], [1.0, 1.0], [0.0, 0.0], ot, None)
+    assert (ot.cpu()[:, 0] - y[:, 0]).abs().max() <= 2e-4 and (ot.cpu()[:, 1] - torch.sigmoid(y[:, 1])).abs().max() <= 1e-4

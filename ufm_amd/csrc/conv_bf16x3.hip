@@ -1,0 +1,256 @@
+// Implicit-GEMM convolution on NHWC activations with fp32-class accuracy on the bf16 matrix cores:
+// every value x is carried as a (hi, lo) pair of bf16 with hi = bf16(x), lo = bf16(x - hi), and each
+// product is evaluated as hi*hi + hi*lo + lo*hi (3 x v_mfma_f32_16x16x32_bf16, fp32 accumulate);
+// the dropped lo*lo term is 2^-16 relative, so a dot product carries ~2^-17 relative error --
+// between TF32 (2^-11, what cuDNN gives the reference's "fp32 island" on NVIDIA by default) and
+// exact fp32, at 5.3x the throughput of the exact-fp32 MFMA (3 x 32 cyc per 32 Kflop vs 512 cyc).
+//
+// The split is done ONCE by the producer: activations live in HBM as two bf16 planes
+// [2][rows][C] (same bytes as fp32), weights are pre-split at pack time, so the main loop is a
+// pure DMA -> LDS -> MFMA pipeline with no conversion VALU work.
+//   * 128 x BN x 32 tile (BN 128/64/32), 4 waves, 16x16x32 MFMA tiles, 2 LDS stages, 2 blocks/CU.
+//   * LDS rows are 64 B (32 channels of one tap); 16-byte chunk index XOR g[(row>>2)&3],
+//     g = {0,2,3,1}: conflict-free ds_read_b128 for the 16-row operand pattern; applied to the DMA
+//     source address (gather + zero halo via per-lane source, as in conv_f32.hip) and to the reads.
+//   * ReLU-on-input uses the sign of hi for both halves (packed 16-bit ops on the fragments).
+//   * epilogue: bias, act, two split residuals, split (hi, lo) store, pixel-shuffle store.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BK = 32;
+
+struct ConvX3Args {
+    const uint16_t* in;   // [2][B*H*W][Cin]
+    const uint16_t* w;    // [2][Cout][KH*KW*Cin]
+    const float* bias;
+    const uint16_t* res1;  // [2][M][Cout] or null
+    const uint16_t* res2;
+    const uint16_t* zero;
+    uint16_t* out;         // [2][Mout][Co]
+    long long in_plane, w_plane, out_plane;
+    int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, M;
+    int relu_in, act, shuffle, Co;
+};
+
+__device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
+
+__device__ __forceinline__ void split_store4(uint16_t* hi_ptr, long long plane, const f32x4& v) {
+    float h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[j] = bf16_to_f32(f32_to_bf16(v[j]));
+        l[j] = v[j] - h[j];
+    }
+    u32x2 ph = {pack_bf16x2(h[0], h[1]), pack_bf16x2(h[2], h[3])};
+    u32x2 pl = {pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3])};
+    *(u32x2*)hi_ptr = ph;
+    *(u32x2*)(hi_ptr + plane) = pl;
+}
+
+__device__ __forceinline__ f32x4 split_load4(const uint16_t* hi_ptr, long long plane) {
+    const u32x2 ph = *(const u32x2*)hi_ptr;
+    const u32x2 pl = *(const u32x2*)(hi_ptr + plane);
+    f32x4 v;
+    v[0] = __uint_as_float(ph[0] << 16) + __uint_as_float(pl[0] << 16);
+    v[1] = __uint_as_float(ph[0] & 0xffff0000u) + __uint_as_float(pl[0] & 0xffff0000u);
+    v[2] = __uint_as_float(ph[1] << 16) + __uint_as_float(pl[1] << 16);
+    v[3] = __uint_as_float(ph[1] & 0xffff0000u) + __uint_as_float(pl[1] & 0xffff0000u);
+    return v;
+}
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvX3Args p) {
+    constexpr int WN = BN >= 64 ? 2 : 1, WM = 4 / WN;
+    constexpr int TM = (BM / WM) / 16, TN = (BN / WN) / 16;
+    constexpr int A_PLANE = BM * BK * 2, W_PLANE = BN * BK * 2;         // bytes per plane per stage
+    constexpr int STAGE_BYTES = 2 * (A_PLANE + W_PLANE);
+    constexpr int W_ROWS_PER_WAVE = BN / 4;                             // 32 / 16 / 8
+    constexpr int W_PIECES = W_ROWS_PER_WAVE >= 16 ? W_ROWS_PER_WAVE / 16 : 1;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntn = p.Cout / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tmi = bid / ntn, tni = bid - tmi * ntn;
+    const int m0 = tmi * BM, n0 = tni * BN;
+    const int cpt = p.Cin / BK;
+    const int nk = p.KH * p.KW * cpt;
+    const size_t ktot = (size_t)p.KH * p.KW * p.Cin;
+
+    // ---- staging: wave w owns tile rows [32w, 32w+32) of A (2 pieces of 16 rows), both planes ----
+    const int srow = lane >> 2, slot = lane & 3;
+    int a_iy0[2], a_ix0[2], a_chunk[2];
+    size_t a_img[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = wave * 32 + i * 16 + srow;
+        a_chunk[i] = (slot ^ swz(r)) * 8;
+        const int m = min(m0 + r, p.M - 1);
+        const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
+        a_iy0[i] = oy * p.stride - p.pad;
+        a_ix0[i] = ox * p.stride - p.pad;
+        a_img[i] = (size_t)b * p.H * p.W;
+    }
+    // weights: BN=128: wave owns rows [32w,32w+32) (2 pieces); BN=64: [16w,16w+16) (1 piece); BN=32: waves 0,1 own 16 rows each
+    const bool w_active = (BN >= 64) || (wave < 2);
+    const uint16_t* gw[W_PIECES];
+#pragma unroll
+    for (int i = 0; i < W_PIECES; ++i) {
+        const int r = (BN >= 64 ? wave * W_ROWS_PER_WAVE : wave * 16) + i * 16 + srow;
+        gw[i] = p.w + (size_t)(n0 + min(r, BN - 1)) * ktot + (slot ^ swz(r)) * 8;
+    }
+    const int w_lds_row0 = (BN >= 64 ? wave * W_ROWS_PER_WAVE : wave * 16);
+
+    auto stage = [&](int buf, int kt) {
+        const int tap = kt / cpt, c0 = (kt - tap * cpt) * BK;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        char* sa = smem + buf * STAGE_BYTES + wave * 32 * 64;  // A hi plane, this wave's rows
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const uint16_t* src = ok ? p.in + (a_img[i] + (size_t)iy * p.W + ix) * p.Cin + c0 + a_chunk[i] : p.zero + a_chunk[i];
+            const uint16_t* src_lo = ok ? src + p.in_plane : src;
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(sa + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src_lo), LDS_PTR(sa + A_PLANE + i * 1024), 16, 0, 0);
+        }
+        if (w_active) {
+            char* sb = smem + buf * STAGE_BYTES + 2 * A_PLANE + w_lds_row0 * 64;
+#pragma unroll
+            for (int i = 0; i < W_PIECES; ++i) {
+                const uint16_t* src = gw[i] + (size_t)kt * BK;
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(sb + i * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + p.w_plane), LDS_PTR(sb + W_PLANE + i * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    // ---- fragment offsets (16x16x32: lane (fr, fq) reads row fr, chunk fq) ----
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 15, fq = lane >> 4;
+    int a_off[TM], w_off[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * (TM * 16) + i * 16 + fr;
+        a_off[i] = r * 64 + ((fq ^ swz(r)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int r = wn * (TN * 16) + i * 16 + fr;
+        w_off[i] = 2 * A_PLANE + r * 64 + ((fq ^ swz(r)) << 4);
+    }
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int m = 0; m < TM; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        const char* s = smem + (kt & 1) * STAGE_BYTES;
+        bf16x8 ah[TM], al[TM], wh[TN], wl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            ah[i] = *(const bf16x8*)(s + a_off[i]);
+            al[i] = *(const bf16x8*)(s + A_PLANE + a_off[i]);
+            if (p.relu_in) {
+                const bf16x8 neg = ah[i] >> 15;  // 0xFFFF where hi < 0 (sign of hi decides for both halves)
+                ah[i] &= ~neg;
+                al[i] &= ~neg;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            wh[i] = *(const bf16x8*)(s + w_off[i]);
+            wl[i] = *(const bf16x8*)(s + W_PLANE + w_off[i]);
+        }
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int m = 0; m < TM; ++m) {
+                acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[n], ah[m], acc[n][m], 0, 0, 0);
+                acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], al[m], acc[n][m], 0, 0, 0);
+                acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], ah[m], acc[n][m], 0, 0, 0);
+            }
+    }
+
+    // ---- epilogue: lane holds out[pixel fr][cb..cb+3] per (n, m) tile ----
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+        const int pix = m0 + wm * (TM * 16) + m * 16 + fr;
+        if (pix >= p.M) continue;
+        int sb = 0, sy = 0, sx = 0;
+        if (p.shuffle) {
+            sx = pix % p.Wo;
+            const int t = pix / p.Wo;
+            sy = t % p.Ho;
+            sb = t / p.Ho;
+        }
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const int cb = n0 + wn * (TN * 16) + n * 16 + fq * 4;
+            f32x4 v = acc[n][m];
+            if (p.shuffle) {
+                const int tapo = cb / p.Co, co = cb - tapo * p.Co;
+                const int kh = tapo / p.shuffle, kw = tapo - kh * p.shuffle;
+                if (p.bias) v += *(const f32x4*)(p.bias + co);
+                const size_t o = (((size_t)sb * (p.Ho * p.shuffle) + sy * p.shuffle + kh) * (p.Wo * p.shuffle) + sx * p.shuffle + kw) * p.Co + co;
+                split_store4(p.out + o, p.out_plane, v);
+                continue;
+            }
+            if (p.bias) v += *(const f32x4*)(p.bias + cb);
+            if (p.act != UFM_ACT_NONE) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act);
+            }
+            const size_t o = (size_t)pix * p.Cout + cb;
+            if (p.res1) v += split_load4(p.res1 + o, p.out_plane);
+            if (p.res2) v += split_load4(p.res2 + o, p.out_plane);
+            split_store4(p.out + o, p.out_plane, v);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ufm_conv2d_nhwc_bf16x3(const uint16_t* in, int B, int H, int W, int Cin, const uint16_t* weight, int Cout,
+                                      int KH, int KW, int stride, int pad, int relu_in, const float* bias, int act,
+                                      const uint16_t* res1, const uint16_t* res2, int shuffle, uint16_t* out,
+                                      const uint16_t* zero_page, void* stream) {
+    UFM_REQUIRE(in && weight && out && zero_page, "ufm_conv2d_nhwc_bf16x3: null pointer");
+    UFM_REQUIRE(B > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, "ufm_conv2d_nhwc_bf16x3: bad geometry");
+    UFM_REQUIRE(Cin % BK == 0 && Cin > 0, "ufm_conv2d_nhwc_bf16x3: Cin=%d must be a multiple of %d", Cin, BK);
+    UFM_REQUIRE(Cout % 32 == 0 && Cout > 0, "ufm_conv2d_nhwc_bf16x3: Cout=%d must be a multiple of 32", Cout);
+    UFM_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)weight % 16) == 0 && ((uintptr_t)out % 8) == 0, "ufm_conv2d_nhwc_bf16x3: misaligned pointer");
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    UFM_REQUIRE(Ho > 0 && Wo > 0, "ufm_conv2d_nhwc_bf16x3: empty output");
+    int Co = Cout;
+    if (shuffle) {
+        UFM_REQUIRE(KH == 1 && KW == 1 && stride == 1 && pad == 0, "ufm_conv2d_nhwc_bf16x3: shuffle mode needs a 1x1 geometry");
+        UFM_REQUIRE(Cout % (shuffle * shuffle) == 0, "ufm_conv2d_nhwc_bf16x3: Cout not divisible by shuffle^2");
+        Co = Cout / (shuffle * shuffle);
+        UFM_REQUIRE(Co % 4 == 0, "ufm_conv2d_nhwc_bf16x3: Co=%d must be a multiple of 4 in shuffle mode", Co);
+        UFM_REQUIRE(!res1 && !res2 && act == UFM_ACT_NONE, "ufm_conv2d_nhwc_bf16x3: shuffle mode supports bias only");
+    }
+    const long long M = (long long)B * Ho * Wo;
+    UFM_REQUIRE(M < (1ll << 31), "ufm_conv2d_nhwc_bf16x3: problem too large");
+    const long long Mout = shuffle ? M * shuffle * shuffle : M;
+    ConvX3Args p{in, weight, bias, res1, res2, zero_page, out,
+                 (long long)B * H * W * Cin, (long long)Cout * KH * KW * Cin, Mout * Co,
+                 B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, (int)M, relu_in, act, shuffle, Co};
+    const int ntm = (int)((M + BM - 1) / BM);
+    if (Cout % 128 == 0) {
+        hipLaunchKernelGGL(conv_x3_kernel<128>, dim3(ntm * (Cout / 128)), dim3(256), 0, (hipStream_t)stream, p);
+    } else if (Cout % 64 == 0) {
+        hipLaunchKernelGGL(conv_x3_kernel<64>, dim3(ntm * (Cout / 64)), dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        hipLaunchKernelGGL(conv_x3_kernel<32>, dim3(ntm * (Cout / 32)), dim3(256), 0, (hipStream_t)stream, p);
+    }
+    UFM_CHECK_LAUNCH("ufm_conv2d_nhwc_bf16x3");
+    return UFM_OK;
+}

@@ -58,7 +58,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             f32x4 y;
 #pragma unroll
             for (int j = 0; j < 4; ++j) y[j] = (v[i][j] - mean) * rstd * wv[j] + bv[j];
-            if (OUT_BF16) {
+            if (OUT_BF16 == 2) {  // split (hi, lo) bf16 planes: hi = bf16(y), lo = bf16(y - hi)
+                float h[4], l[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    h[j] = bf16_to_f32(f32_to_bf16(y[j]));
+                    l[j] = y[j] - h[j];
+                }
+                u32x2 ph = {pack_bf16x2(h[0], h[1]), pack_bf16x2(h[2], h[3])};
+                u32x2 pl = {pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3])};
+                uint16_t* o = (uint16_t*)out + (size_t)row * ldo + c * 4;
+                *(u32x2*)o = ph;
+                *(u32x2*)(o + (size_t)rows_out * ldo) = pl;
+            } else if (OUT_BF16 == 1) {
                 u32x2 pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
                 *(u32x2*)((uint16_t*)out + (size_t)row * ldo + c * 4) = pk;
             } else {
@@ -87,9 +99,11 @@ extern "C" int ufm_layernorm(const float* x, int ldx, const int32_t* row_index, 
     UFM_REQUIRE(rows_out > 0, "ufm_layernorm: rows_out=%d", rows_out);
     UFM_REQUIRE(D % 4 == 0 && D <= MAX_VPL * 256 && D > 0, "ufm_layernorm: D=%d must be a multiple of 4 and <= %d", D, MAX_VPL * 256);
     UFM_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && ldx >= D && ldo >= D, "ufm_layernorm: bad ldx/ldo %d/%d", ldx, ldo);
-    UFM_REQUIRE(out_dtype == UFM_F32 || out_dtype == UFM_BF16, "ufm_layernorm: bad out_dtype");
+    UFM_REQUIRE(out_dtype == UFM_F32 || out_dtype == UFM_BF16 || out_dtype == UFM_BF16X2, "ufm_layernorm: bad out_dtype");
     dim3 grid((rows_out + 3) / 4), block(256);
-    if (out_dtype == UFM_BF16)
+    if (out_dtype == UFM_BF16X2)
+        hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, (hipStream_t)stream, x, ldx, row_index, rows_out, D, weight, bias, eps, out, ldo);
+    else if (out_dtype == UFM_BF16)
         hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, (hipStream_t)stream, x, ldx, row_index, rows_out, D, weight, bias, eps, out, ldo);
     else
         hipLaunchKernelGGL(layernorm_kernel<0>, grid, block, 0, (hipStream_t)stream, x, ldx, row_index, rows_out, D, weight, bias, eps, out, ldo);

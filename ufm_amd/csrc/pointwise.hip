@@ -52,10 +52,35 @@ __global__ __launch_bounds__(256) void patchify_kernel(const void* img, int in_d
     }
 }
 
+__device__ __forceinline__ f32x4 ld_split4(const uint16_t* hi_ptr, size_t plane) {
+    const u32x2 ph = *(const u32x2*)hi_ptr;
+    const u32x2 pl = *(const u32x2*)(hi_ptr + plane);
+    f32x4 v;
+    v[0] = __uint_as_float(ph[0] << 16) + __uint_as_float(pl[0] << 16);
+    v[1] = __uint_as_float(ph[0] & 0xffff0000u) + __uint_as_float(pl[0] & 0xffff0000u);
+    v[2] = __uint_as_float(ph[1] << 16) + __uint_as_float(pl[1] << 16);
+    v[3] = __uint_as_float(ph[1] & 0xffff0000u) + __uint_as_float(pl[1] & 0xffff0000u);
+    return v;
+}
+__device__ __forceinline__ void st_split4(uint16_t* hi_ptr, size_t plane, const f32x4& v) {
+    float h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[j] = bf16_to_f32(f32_to_bf16(v[j]));
+        l[j] = v[j] - h[j];
+    }
+    u32x2 ph = {pack_bf16x2(h[0], h[1]), pack_bf16x2(h[2], h[3])};
+    u32x2 pl = {pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3])};
+    *(u32x2*)hi_ptr = ph;
+    *(u32x2*)(hi_ptr + plane) = pl;
+}
+
 // align_corners=True bilinear, NHWC, float4 over channels.
 // (Ho, Wo) is the stored extent; sy/sx come from the FULL output size (a cropped store, DPT refinenet4).
-__global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ in, int B, int H, int W, int C,
-                                                       float* __restrict__ out, int Ho, int Wo, float sy, float sx) {
+template <int SPLIT>
+__global__ __launch_bounds__(256) void upsample_kernel(const void* __restrict__ in_, int B, int H, int W, int C,
+                                                       void* __restrict__ out_, int Ho, int Wo, float sy, float sx) {
+    const size_t in_plane = (size_t)B * H * W * C, out_plane = (size_t)B * Ho * Wo * C;
     const int cq = C >> 2;
     const size_t total = (size_t)B * Ho * Wo * cq;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
@@ -68,15 +93,30 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
         const int y0 = (int)fy, x0 = (int)fx;
         const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
         const float ly1 = fy - y0, lx1 = fx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-        const float* base = in + (size_t)b * H * W * C + c4 * 4;
-        const f32x4 v00 = *(const f32x4*)(base + ((size_t)y0 * W + x0) * C);
-        const f32x4 v01 = *(const f32x4*)(base + ((size_t)y0 * W + x1) * C);
-        const f32x4 v10 = *(const f32x4*)(base + ((size_t)y1 * W + x0) * C);
-        const f32x4 v11 = *(const f32x4*)(base + ((size_t)y1 * W + x1) * C);
+        const size_t boff = (size_t)b * H * W * C + c4 * 4;
+        const size_t o00 = boff + ((size_t)y0 * W + x0) * C, o01 = boff + ((size_t)y0 * W + x1) * C;
+        const size_t o10 = boff + ((size_t)y1 * W + x0) * C, o11 = boff + ((size_t)y1 * W + x1) * C;
+        f32x4 v00, v01, v10, v11;
+        if (SPLIT) {
+            const uint16_t* in = (const uint16_t*)in_;
+            v00 = ld_split4(in + o00, in_plane);
+            v01 = ld_split4(in + o01, in_plane);
+            v10 = ld_split4(in + o10, in_plane);
+            v11 = ld_split4(in + o11, in_plane);
+        } else {
+            const float* in = (const float*)in_;
+            v00 = *(const f32x4*)(in + o00);
+            v01 = *(const f32x4*)(in + o01);
+            v10 = *(const f32x4*)(in + o10);
+            v11 = *(const f32x4*)(in + o11);
+        }
         f32x4 r;
 #pragma unroll
         for (int j = 0; j < 4; ++j) r[j] = ly0 * (lx0 * v00[j] + lx1 * v01[j]) + ly1 * (lx0 * v10[j] + lx1 * v11[j]);
-        *(f32x4*)(out + pix * C + c4 * 4) = r;
+        if (SPLIT)
+            st_split4((uint16_t*)out_ + pix * C + c4 * 4, out_plane, r);
+        else
+            *(f32x4*)((float*)out_ + pix * C + c4 * 4) = r;
     }
 }
 
@@ -87,15 +127,16 @@ struct TailArgs {
 };
 
 // one thread per pixel; x row is Cin floats (Cin % 4 == 0, <= 64); w/b from global (L1/L2 resident).
-__global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict__ x, int P, int HW, int Cin,
+template <int SPLIT>
+__global__ __launch_bounds__(256) void head_tail_kernel(const void* __restrict__ x_, int P, int HW, int Cin,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
                                                         int Cout, TailArgs ta, float* __restrict__ out,
                                                         float* __restrict__ out_logits) {
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        const float* xr = x + (size_t)p * Cin;
         for (int k = 0; k < Cin; k += 4) {
-            const f32x4 xv = *(const f32x4*)(xr + k);
+            const f32x4 xv = SPLIT ? ld_split4((const uint16_t*)x_ + (size_t)p * Cin + k, (size_t)P * Cin)
+                                   : *(const f32x4*)((const float*)x_ + (size_t)p * Cin + k);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if (c < Cout) {
@@ -286,8 +327,9 @@ extern "C" int ufm_patchify(const void* img, int in_dtype, int in_layout, int B,
     return UFM_OK;
 }
 
-extern "C" int ufm_upsample_bilinear_nhwc(const float* in, int B, int H, int W, int C, float* out, int Ho, int Wo,
+extern "C" int ufm_upsample_bilinear_nhwc(const void* in, int dtype, int B, int H, int W, int C, void* out, int Ho, int Wo,
                                           int crop_h, int crop_w, void* stream) {
+    UFM_REQUIRE(dtype == UFM_F32 || dtype == UFM_BF16X2, "ufm_upsample_bilinear_nhwc: dtype must be UFM_F32 or UFM_BF16X2");
     UFM_REQUIRE(in && out, "ufm_upsample_bilinear_nhwc: null pointer");
     UFM_REQUIRE(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && C % 4 == 0, "ufm_upsample_bilinear_nhwc: bad shape");
     UFM_REQUIRE(crop_h >= 0 && crop_h <= Ho && crop_w >= 0 && crop_w <= Wo, "ufm_upsample_bilinear_nhwc: bad crop");
@@ -295,12 +337,15 @@ extern "C" int ufm_upsample_bilinear_nhwc(const float* in, int B, int H, int W, 
     const float sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
     const int Hs = crop_h > 0 ? crop_h : Ho, Ws = crop_w > 0 ? crop_w : Wo;
     const size_t total = (size_t)B * Hs * Ws * (C / 4);
-    hipLaunchKernelGGL(upsample_kernel, stream_grid(total), dim3(256), 0, (hipStream_t)stream, in, B, H, W, C, out, Hs, Ws, sy, sx);
+    if (dtype == UFM_BF16X2)
+        hipLaunchKernelGGL(upsample_kernel<1>, stream_grid(total), dim3(256), 0, (hipStream_t)stream, in, B, H, W, C, out, Hs, Ws, sy, sx);
+    else
+        hipLaunchKernelGGL(upsample_kernel<0>, stream_grid(total), dim3(256), 0, (hipStream_t)stream, in, B, H, W, C, out, Hs, Ws, sy, sx);
     UFM_CHECK_LAUNCH("ufm_upsample_bilinear_nhwc");
     return UFM_OK;
 }
 
-extern "C" int ufm_head_tail(const float* x, int P, int HW, int Cin, const float* w, const float* b, int Cout,
+extern "C" int ufm_head_tail(const void* x, int in_dtype, int P, int HW, int Cin, const float* w, const float* b, int Cout,
                              const int32_t* kind_host, const float* a_host, const float* d_host, float* out,
                              float* out_logits, void* stream) {
     UFM_REQUIRE(x && w && b && out && kind_host && a_host && d_host, "ufm_head_tail: null pointer");
@@ -311,7 +356,11 @@ extern "C" int ufm_head_tail(const float* x, int P, int HW, int Cin, const float
         ta.a[c] = c < Cout ? a_host[c] : 1.f;
         ta.d[c] = c < Cout ? d_host[c] : 0.f;
     }
-    hipLaunchKernelGGL(head_tail_kernel, stream_grid((size_t)P), dim3(256), 0, (hipStream_t)stream, x, P, HW, Cin, w, b, Cout, ta, out, out_logits);
+    UFM_REQUIRE(in_dtype == UFM_F32 || in_dtype == UFM_BF16X2, "ufm_head_tail: in_dtype must be UFM_F32 or UFM_BF16X2");
+    if (in_dtype == UFM_BF16X2)
+        hipLaunchKernelGGL(head_tail_kernel<1>, stream_grid((size_t)P), dim3(256), 0, (hipStream_t)stream, x, P, HW, Cin, w, b, Cout, ta, out, out_logits);
+    else
+        hipLaunchKernelGGL(head_tail_kernel<0>, stream_grid((size_t)P), dim3(256), 0, (hipStream_t)stream, x, P, HW, Cin, w, b, Cout, ta, out, out_logits);
     UFM_CHECK_LAUNCH("ufm_head_tail");
     return UFM_OK;
 }

@@ -58,10 +58,18 @@ class _Blk:
         self.ls2 = _f32(blk.ls2.gamma, dev) if hasattr(blk.ls2, "gamma") else None
 
 
-class _Conv:
-    """Conv2d packed [Cout][KH][KW][Cin]; ConvTranspose2d(k == s) packed [(kh,kw,co)][Cin]."""
+def _split_bf16(w: torch.Tensor) -> torch.Tensor:
+    """fp32 -> UFM_BF16X2: stack(hi = bf16(w), lo = bf16(w - hi))."""
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    return torch.stack([hi, lo], dim=0).contiguous()
 
-    def __init__(self, conv: nn.Module, dev):
+
+class _Conv:
+    """Conv2d packed [Cout][KH][KW][Cin]; ConvTranspose2d(k == s) packed [(kh,kw,co)][Cin].
+    split=True stores the weight pre-split in the UFM_BF16X2 format for the bf16x3 kernel."""
+
+    def __init__(self, conv: nn.Module, dev, split: bool = False):
         w = conv.weight.detach().to(device=dev, dtype=torch.float32)
         self.b = _f32(conv.bias, dev) if conv.bias is not None else None
         if isinstance(conv, nn.ConvTranspose2d):
@@ -73,27 +81,30 @@ class _Conv:
             co, cin, kh, kw = w.shape
             self.shuffle, self.cin, self.cout, self.k, self.stride, self.pad = 0, cin, co, kh, conv.stride[0], conv.padding[0]
             self.w = w.permute(0, 2, 3, 1).contiguous()
+        if split:
+            self.w = _split_bf16(self.w)
 
 
 class _Head:
-    def __init__(self, head: nn.Sequential, dev):
+    def __init__(self, head: nn.Sequential, dev, split: bool = False):
+        _C = lambda m, d: _Conv(m, d, split)  # noqa: E731
         feat, proc = head[0][0], head[0][1]
         self.feature_dim, self.layer_dims = feat.feature_dim, feat.layer_dims
         self.hooks = feat.hooks
-        self.act = [[_Conv(m, dev) for m in seq] for seq in feat.act_postprocess]
-        self.rn = [_Conv(getattr(feat.scratch, f"layer{i + 1}_rn"), dev) for i in range(4)]
+        self.act = [[_C(m, dev) for m in seq] for seq in feat.act_postprocess]
+        self.rn = [_C(getattr(feat.scratch, f"layer{i + 1}_rn"), dev) for i in range(4)]
         self.fuse = []
         for i in range(4):
             f = getattr(feat.scratch, f"refinenet{i + 1}")
             self.fuse.append(
                 dict(
-                    out=_Conv(f.out_conv, dev),
-                    r1=(_Conv(f.resConfUnit1.conv1, dev), _Conv(f.resConfUnit1.conv2, dev)),
-                    r2=(_Conv(f.resConfUnit2.conv1, dev), _Conv(f.resConfUnit2.conv2, dev)),
+                    out=_C(f.out_conv, dev),
+                    r1=(_C(f.resConfUnit1.conv1, dev), _C(f.resConfUnit1.conv2, dev)),
+                    r2=(_C(f.resConfUnit2.conv1, dev), _C(f.resConfUnit2.conv2, dev)),
                 )
             )
-        self.p_conv1 = _Conv(proc.conv1, dev)
-        self.p_conv2a = _Conv(proc.conv2[0], dev)
+        self.p_conv1 = _C(proc.conv1, dev)
+        self.p_conv2a = _C(proc.conv2[0], dev)
         last = proc.conv2[2]
         self.tail_w = _f32(last.weight.reshape(last.weight.shape[0], -1), dev)
         self.tail_b = _f32(last.bias, dev)
@@ -152,9 +163,11 @@ class Engine:
         self.info_norm = (_f32(info.norm.weight, dev), _f32(info.norm.bias, dev))
         if info.max_num_views < 2:
             raise ValueError("info sharing needs max_num_views >= 2")
-        self.heads = {"head1": _Head(m.head1, dev)}
+        # DPT heads: exact-fp32 MFMA in "parity"; bf16x3 split precision (UFM_BF16X2 activations) in "fast"
+        self.head_split = self.numerics == "fast"
+        self.heads = {"head1": _Head(m.head1, dev, self.head_split)}
         if hasattr(m, "uncertainty_head"):
-            self.heads["uncertainty_head"] = _Head(m.uncertainty_head, dev)
+            self.heads["uncertainty_head"] = _Head(m.uncertainty_head, dev, self.head_split)
         self.refine = hasattr(m, "classification_head")
         if self.refine:
             ch = m.classification_head
@@ -237,7 +250,20 @@ class Engine:
             hip.conv2d(x, 1, 1, M, lin.k, lin.w, lin.n, 1, 1, 1, 0, out, self.zero, bias=lin.b, act=act, gamma=gamma, res1=res)
 
     def conv(self, x, B, H, W, c: _Conv, out, *, relu_in=False, act=hip.ACT_NONE, res1=None, res2=None):
-        hip.conv2d(x, B, H, W, c.cin, c.w, c.cout, c.k, c.k, c.stride, c.pad, out, self.zero, relu_in=relu_in, bias=c.b, act=act, res1=res1, res2=res2, shuffle=c.shuffle)
+        fn = hip.conv2d_x3 if c.w.dtype == torch.bfloat16 else hip.conv2d
+        fn(x, B, H, W, c.cin, c.w, c.cout, c.k, c.k, c.stride, c.pad, out, self.zero, relu_in=relu_in, bias=c.b, act=act, res1=res1, res2=res2, shuffle=c.shuffle)
+
+    def hbuf(self, name: str, shape: Tuple[int, ...]) -> torch.Tensor:
+        """Head activation buffer: fp32 [shape] or the split format (2, *shape) bf16."""
+        if self.head_split:
+            return self.buf(name, (2,) + tuple(shape), torch.bfloat16)
+        return self.buf(name, shape)
+
+    def level_ln(self, x, D, row_index, rows, w, b, name: str) -> torch.Tensor:
+        """LayerNorm + row gather into a head-format feature level."""
+        t = self.hbuf(name, (rows, D))
+        hip.layernorm(x, D, row_index, rows, D, w, b, 1e-6, t, split=self.head_split)
+        return t
 
     # ------------------------------------------------------------------ transformer
     def _blocks(self, blocks: List[_Blk], x, Bseq: int, N: int, D: int, heads: int, on_block):
@@ -279,19 +305,19 @@ class Engine:
         r = []
         for i in range(4):
             lvl = levels[hw.hooks[i]]
-            t = self.buf(f"{tag}_act{i}", (B, gh, gw, ld[i]))
+            t = self.hbuf(f"{tag}_act{i}", (B, gh, gw, ld[i]))
             self.conv(lvl, B, gh, gw, hw.act[i][0], t)
             u = t
             if i < 2 or i == 3:
-                u = self.buf(f"{tag}_post{i}", (B, sizes[i][0], sizes[i][1], ld[i]))
+                u = self.hbuf(f"{tag}_post{i}", (B, sizes[i][0], sizes[i][1], ld[i]))
                 self.conv(t, B, gh, gw, hw.act[i][1], u)
-            ri = self.buf(f"{tag}_rn{i}", (B, sizes[i][0], sizes[i][1], Fd))
+            ri = self.hbuf(f"{tag}_rn{i}", (B, sizes[i][0], sizes[i][1], Fd))
             self.conv(u, B, sizes[i][0], sizes[i][1], hw.rn[i], ri)
             r.append(ri)
 
         def rcu(x, pair, h, w, name, extra_res=None):
-            t1 = self.buf(f"{tag}_{name}_t", (B, h, w, Fd))
-            o = self.buf(f"{tag}_{name}_o", (B, h, w, Fd))
+            t1 = self.hbuf(f"{tag}_{name}_t", (B, h, w, Fd))
+            o = self.hbuf(f"{tag}_{name}_o", (B, h, w, Fd))
             self.conv(x, B, h, w, pair[0], t1, relu_in=True)
             self.conv(t1, B, h, w, pair[1], o, relu_in=True, res1=x, res2=extra_res)
             return o
@@ -306,21 +332,21 @@ class Engine:
                 s = rcu(r[lvl], f["r1"], h, w, f"f{lvl}a", extra_res=path)  # path + resConfUnit1(r)
             o = rcu(s, f["r2"], h, w, f"f{lvl}b")
             # out_conv (1x1) commutes with the bilinear x2 (weights sum to 1): run it at low resolution
-            c = self.buf(f"{tag}_f{lvl}c", (B, h, w, Fd))
+            c = self.hbuf(f"{tag}_f{lvl}c", (B, h, w, Fd))
             self.conv(o, B, h, w, f["out"], c)
             if lvl == 3:
                 th, tw = sizes[2]  # refinenet4 output is cropped to layer-3's grid
-                path = self.buf(f"{tag}_p{lvl}", (B, th, tw, Fd))
+                path = self.hbuf(f"{tag}_p{lvl}", (B, th, tw, Fd))
                 hip.upsample_bilinear(c, B, h, w, Fd, path, 2 * h, 2 * w, th, tw)
             else:
-                path = self.buf(f"{tag}_p{lvl}", (B, 2 * h, 2 * w, Fd))
+                path = self.hbuf(f"{tag}_p{lvl}", (B, 2 * h, 2 * w, Fd))
                 hip.upsample_bilinear(c, B, h, w, Fd, path, 2 * h, 2 * w)
         h8, w8 = 2 * sizes[0][0], 2 * sizes[0][1]
-        c1 = self.buf(f"{tag}_pc1", (B, h8, w8, hw.p_conv1.cout))
+        c1 = self.hbuf(f"{tag}_pc1", (B, h8, w8, hw.p_conv1.cout))
         self.conv(path, B, h8, w8, hw.p_conv1, c1)
-        up = self.buf(f"{tag}_up", (B, H, W, hw.p_conv1.cout))
+        up = self.hbuf(f"{tag}_up", (B, H, W, hw.p_conv1.cout))
         hip.upsample_bilinear(c1, B, h8, w8, hw.p_conv1.cout, up, H, W)
-        c2 = self.buf(f"{tag}_pc2", (B, H, W, hw.p_conv2a.cout))
+        c2 = self.hbuf(f"{tag}_pc2", (B, H, W, hw.p_conv2a.cout))
         self.conv(up, B, H, W, hw.p_conv2a, c2, act=hip.ACT_RELU)
         out = torch.empty((B, hw.tail_cout, H, W), device=self.dev, dtype=torch.float32)
         logits = torch.empty_like(out) if 1 in hw.kinds else None
@@ -363,17 +389,17 @@ class Engine:
         nw, nb = self.enc_norm
         enc_first = None
         last_i = len(self.enc_blocks) - 1
-        lvl0 = self.buf("lvl0", (B * Np, D))
+        lvl0 = None
         enc_info = self.buf("enc_info", (B * 2 * Np, D), self.adt)
 
         def on_enc(i, xx):
-            nonlocal enc_first
+            nonlocal enc_first, lvl0
             if self.refine and i == self.enc_indices[0]:
                 enc_first = self.buf("enc_first", (B2 * Np, D))
                 hip.layernorm(xx, D, idx["enc_all"], B2 * Np, D, nw, nb, 1e-6, enc_first)
             if i == self.enc_indices[-1]:
                 hip.layernorm(xx, D, idx["enc_info"], B * 2 * Np, D, nw, nb, 1e-6, enc_info)
-                hip.layernorm(xx, D, idx["enc_v1"], B * Np, D, nw, nb, 1e-6, lvl0)
+                lvl0 = self.level_ln(xx, D, idx["enc_v1"], B * Np, nw, nb, "lvl0")
 
         blocks = self.enc_blocks[: self.enc_indices[-1] + 1]  # blocks past the last returned index never matter
         self._blocks(blocks, x, B2, N, D, self.enc_heads, on_enc)
@@ -399,15 +425,12 @@ class Engine:
 
         def on_info(i, yy):
             if i in self.info_indices:
-                t = self.buf(f"lvl_i{len(inter)}", (B * Np, Di))
-                hip.layernorm(yy, Di, idx["info_v1"], B * Np, Di, inw, inb, 1e-6, t)
-                inter.append(t)
+                inter.append(self.level_ln(yy, Di, idx["info_v1"], B * Np, inw, inb, f"lvl_i{len(inter)}"))
 
         self._blocks(self.info_blocks, y, B, 2 * Np, Di, self.info_heads, on_info)
         if len(inter) != 2:
             raise ValueError("info_sharing.indices must name two blocks (ufm.py:605-606 reads intermediates [0] and [1])")
-        lvl3 = self.buf("lvl3", (B * Np, Di))
-        hip.layernorm(y, Di, idx["info_v1"], B * Np, Di, inw, inb, 1e-6, lvl3)
+        lvl3 = self.level_ln(y, Di, idx["info_v1"], B * Np, inw, inb, "lvl3")
         levels = [lvl0, inter[0], inter[1], lvl3]  # ufm.py:603-608 (view-1 pyramid only; view 2's is never decoded)
         dims = [D, Di, Di, Di]
 
@@ -416,13 +439,15 @@ class Engine:
             out[tag] = self._head(hw, tag, levels, dims, B, gh, gw, H, W)
 
         if self.refine:  # ufm.py:949-1007
+            lvl3a = self.buf("lvl3_v1_f32", (B * Np, Di))
+            hip.layernorm(y, Di, idx["info_v1"], B * Np, Di, inw, inb, 1e-6, lvl3a)
             lvl3b = self.buf("lvl3_v2", (B * Np, Di))
             hip.layernorm(y, Di, idx["info_v2"], B * Np, Di, inw, inb, 1e-6, lvl3b)
             C1 = D + Di
             cat = self.buf("cls_in", (B2 * Np, C1))
             # torch.cat along channels == strided row copies: enc_first | info_final, views stacked on batch
             hip.add_rows(enc_first, D, None, 0, cat, C1, 0, B2 * Np, D)
-            hip.add_rows(lvl3, Di, None, 0, cat[:, D:], C1, 0, B * Np, Di)
+            hip.add_rows(lvl3a, Di, None, 0, cat[:, D:], C1, 0, B * Np, Di)
             hip.add_rows(lvl3b, Di, None, 0, cat[B * Np :, D:], C1, 0, B * Np, Di)
             hidden = self.buf("cls_hid", (B2 * Np, self.cls_fc1.n))
             self.linear(cat, self.cls_fc1, B2 * Np, hidden, act=hip.ACT_GELU)

@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libufm_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, BF16X2 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 
 _lib: Optional[C.CDLL] = None
@@ -36,8 +36,9 @@ SIGNATURES = {
     "ufm_attention_bf16": [_vp, _vp, _i, _i, _i, _f, _vp],
     "ufm_attention_f32": [_vp, _vp, _i, _i, _i, _f, _vp],
     "ufm_conv2d_nhwc_f32": [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp],
-    "ufm_upsample_bilinear_nhwc": [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp],
-    "ufm_head_tail": [_vp, _i, _i, _i, _vp, _vp, _i, _ip, _fp3, _fp3, _vp, _vp, _vp],
+    "ufm_conv2d_nhwc_bf16x3": [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp],
+    "ufm_upsample_bilinear_nhwc": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp],
+    "ufm_head_tail": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _ip, _fp3, _fp3, _vp, _vp, _vp],
     "ufm_unmap_flow": [_vp, _i, _i, _i, _ip, _ip, _ip, _i, _i, _vp, _vp, _vp],
     "ufm_unmap_channels": [_vp, _i, _i, _i, _i, _ip, _ip, _i, _i, _fp3, _vp, _vp, _vp],
     "ufm_refine": [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
@@ -167,9 +168,10 @@ def gemm_bf16(A, W, M, N, K, out, *, bias=None, act=ACT_NONE, gamma=None, res=No
     )
 
 
-def layernorm(x, ldx, row_index, rows_out, D, weight, bias, eps, out, ldo=None):
-    _t("ufm_layernorm", rows_out * D * (4.0 + out.element_size()))
-    _check(lib().ufm_layernorm(_p(x), ldx, _p(row_index), rows_out, D, _p(weight), _p(bias), eps, _p(out), _dt(out), ldo or D, _stream()), "ufm_layernorm")
+def layernorm(x, ldx, row_index, rows_out, D, weight, bias, eps, out, ldo=None, split=False):
+    """split=True: `out` is a (2, rows_out, D) bf16 tensor in the UFM_BF16X2 format."""
+    _t("ufm_layernorm", rows_out * D * (4.0 + (4 if split else out.element_size())))
+    _check(lib().ufm_layernorm(_p(x), ldx, _p(row_index), rows_out, D, _p(weight), _p(bias), eps, _p(out), BF16X2 if split else _dt(out), ldo or D, _stream()), "ufm_layernorm")
 
 
 def fill_rows(out, ldo, n_groups, group_stride_rows, src, D):
@@ -185,6 +187,7 @@ def attention(qkv, out, B, N, H, scale):
         _t("ufm_attention_bf16", 4.0 * B * H * N * N * 64)
         _check(lib().ufm_attention_bf16(_p(qkv), _p(out), B, N, H, scale, _stream()), "ufm_attention_bf16")
     else:
+        _t("ufm_attention_f32", 4.0 * B * H * N * N * 64)
         _check(lib().ufm_attention_f32(_p(qkv), _p(out), B, N, H, scale, _stream()), "ufm_attention_f32")
 
 
@@ -197,13 +200,24 @@ def conv2d(x, B, H, W, Cin, weight, Cout, KH, KW, stride, pad, out, zero_page, *
     )
 
 
+def conv2d_x3(x, B, H, W, Cin, weight, Cout, KH, KW, stride, pad, out, zero_page, *, relu_in=False, bias=None, act=ACT_NONE, res1=None, res2=None, shuffle=0):
+    """bf16x3 split-precision conv; x / weight / res / out are (2, ...) bf16 tensors (UFM_BF16X2)."""
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    _t("ufm_conv2d_nhwc_bf16x3", 2.0 * B * Ho * Wo * Cout * KH * KW * Cin)
+    _check(
+        lib().ufm_conv2d_nhwc_bf16x3(_p(x), B, H, W, Cin, _p(weight), Cout, KH, KW, stride, pad, int(relu_in), _p(bias), act, _p(res1), _p(res2), shuffle, _p(out), _p(zero_page), _stream()),
+        "ufm_conv2d_nhwc_bf16x3",
+    )
+
+
 def upsample_bilinear(x, B, H, W, C, out, Ho, Wo, crop_h=0, crop_w=0):
+    split = x.dtype == torch.bfloat16
     _t("ufm_upsample_bilinear_nhwc", 4.0 * B * C * (H * W + (crop_h or Ho) * (crop_w or Wo)))
-    _check(lib().ufm_upsample_bilinear_nhwc(_p(x), B, H, W, C, _p(out), Ho, Wo, crop_h, crop_w, _stream()), "ufm_upsample_bilinear_nhwc")
+    _check(lib().ufm_upsample_bilinear_nhwc(_p(x), BF16X2 if split else F32, B, H, W, C, _p(out), Ho, Wo, crop_h, crop_w, _stream()), "ufm_upsample_bilinear_nhwc")
 
 
 def head_tail(x, P, HW, Cin, w, b, Cout, kinds, a, d, out, out_logits=None):
-    _check(lib().ufm_head_tail(_p(x), P, HW, Cin, _p(w), _p(b), Cout, _i4(kinds), _f3(a), _f3(d), _p(out), _p(out_logits), _stream()), "ufm_head_tail")
+    _check(lib().ufm_head_tail(_p(x), BF16X2 if x.dtype == torch.bfloat16 else F32, P, HW, Cin, _p(w), _p(b), Cout, _i4(kinds), _f3(a), _f3(d), _p(out), _p(out_logits), _stream()), "ufm_head_tail")
 
 
 def unmap_flow(flow, B, h, w, rep0, src0, src1, H0, W0, out, valid=None):
