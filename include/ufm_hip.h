@@ -93,6 +93,9 @@ int ufm_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M,
                   int res_row_mod, void* out, int out_dtype, int ldo, int out_row_group,
                   void* stream);
 
+/* Tuning hook: force_small=1 pins ufm_gemm_bf16 to its 128x128 kernel (A/B timing in one process). */
+int ufm_debug_set_gemm_variant(int force_small);
+
 /* =====================================================================================
  * LayerNorm over the channel dim, eps inside the sqrt ([U] Block.norm1/norm2, encoder .norm,
  * info-sharing .norm; nn.LayerNorm(eps=1e-6)).  x: fp32 [*, D] rows of stride ldx.

@@ -78,6 +78,26 @@ def test_gemm_bf16(hip, M, N, K, act, use_gamma, use_res, out_bf16, row_mod, row
     assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("M,N,K,out_bf16", [(256 * 70 + 13, 768, 192, True), (256 * 64 + 200, 1024, 640, False)])
+def test_gemm_large_tile_variants(hip, variant, M, N, K, out_bf16):
+    """All three tile shapes (128x128 / 256x128 3-stage / 256x256 4-stage ring) against the same fp64 statement,
+    ragged M, short and long K (prologue/epilogue of the DMA ring)."""
+    lib = hip.lib()
+    A = bf16r(rnd(M, K, seed=1))
+    W = bf16r(rnd(N, K, seed=2, scale=K**-0.5))
+    bias, gamma, res = rnd(N, seed=3, scale=0.1), 1 + rnd(N, seed=4, scale=0.1), rnd(M, N, seed=5)
+    ref = (A.double() @ W.double().T + bias.double()) * gamma.double() + res.double()
+    out = torch.zeros(M, N, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=DEV)
+    lib.ufm_debug_set_gemm_variant(variant)
+    try:
+        hip.gemm_bf16(A.to(DEV).bfloat16(), W.to(DEV).bfloat16(), M, N, K, out, bias=bias.to(DEV), gamma=gamma.to(DEV), res=res.to(DEV))
+    finally:
+        lib.ufm_debug_set_gemm_variant(0)
+    err = (out.float().cpu().double() - ref).abs().max().item()
+    assert err <= (3e-2 if out_bf16 else 3e-4) * max(1.0, ref.abs().max().item()), err
+
+
 def test_gemm_in_place_residual(hip):
     M, N, K = 200, 128, 64
     A, W = bf16r(rnd(M, K, seed=1)), bf16r(rnd(N, K, seed=2))

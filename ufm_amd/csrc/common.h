@@ -48,6 +48,16 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// Branch-free GELU for bf16 outputs: erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, three
+// orders below bf16 resolution); ~14 VALU ops vs the branchy libm erff.
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float e = 1.0f - poly * __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+    return 0.5f * x * (1.0f + copysignf(e, x));
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == UFM_ACT_GELU) return gelu_erf(v);
     if (act == UFM_ACT_RELU) return fmaxf(v, 0.0f);
