@@ -95,6 +95,8 @@ int ufm_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M,
 
 /* Tuning hook: force_small=1 pins ufm_gemm_bf16 to its 128x128 kernel (A/B timing in one process). */
 int ufm_debug_set_gemm_variant(int force_small);
+/* Tuning hook (timing diagnostics only; 0 = normal). */
+int ufm_debug_set_attn_variant(int v);
 
 /* =====================================================================================
  * LayerNorm over the channel dim, eps inside the sqrt ([U] Block.norm1/norm2, encoder .norm,
@@ -124,6 +126,9 @@ int ufm_add_rows(const float* a, int lda, const float* tab, int ldtab, int tab_m
  * qkv: bf16 [B*N][3*H*64] laid out (which, head, d) per row = the raw output of the qkv Linear.
  * out: bf16 [B*N][H*64].  Flash-style: K/V tiles staged in LDS, online softmax in registers,
  * S = Q K^T and O = P V on MFMA (32x32x16 bf16, fp32 accumulate); N arbitrary (tail masked).
+ * scale > 0: softmax scale applied in-kernel.  scale == 0: the Q columns are PRE-SCALED by
+ * softmax_scale*log2(e) (ufm_gemm_bf16's per-column gamma on the QKV projection does it before the
+ * bf16 rounding) and the faster log2-domain kernel with deferred rescaling runs.
  * ===================================================================================== */
 int ufm_attention_bf16(const uint16_t* qkv, uint16_t* out, int B, int N, int H, float scale,
                        void* stream);

@@ -78,7 +78,7 @@ def test_gemm_bf16(hip, M, N, K, act, use_gamma, use_res, out_bf16, row_mod, row
     assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 28])
 @pytest.mark.parametrize("M,N,K,out_bf16", [(256 * 70 + 13, 768, 192, True), (256 * 64 + 200, 1024, 640, False)])
 def test_gemm_large_tile_variants(hip, variant, M, N, K, out_bf16):
     """All three tile shapes (128x128 / 256x128 3-stage / 256x256 4-stage ring) against the same fp64 statement,
@@ -143,6 +143,41 @@ def test_attention_bf16(hip, B, N, H):
     hip.attention(qkv.to(DEV).bfloat16(), out, B, N, H, 0.125)
     err = (out.float().cpu().double() - ref).abs().max().item()
     assert err <= 2e-2, err  # P and O are rounded to bf16 (8 bits): |O| <~ 1
+
+
+@pytest.mark.parametrize("B,N,H", [(1, 17, 1), (2, 100, 2), (2, 1370, 2), (1, 2738, 3), (1, 64, 1), (1, 129, 1)])
+def test_attention_bf16_prescaled_log2_kernel(hip, B, N, H):
+    """scale == 0 path: Q columns pre-multiplied by scale*log2(e) (what the QKV GEMM epilogue does), deferred rescale."""
+    qkv = rnd(B * N, 3 * H * 64, seed=N, scale=1.5)
+    qkv_b = bf16r(qkv)
+    ref = attn_ref(qkv_b, B, N, H, 0.125)
+    pre = qkv.clone().reshape(B * N, 3, H * 64)
+    pre[:, 0] = bf16r(pre[:, 0]) * (0.125 * 1.4426950408889634)  # same values the epilogue would round once
+    pre = bf16r(pre.reshape(B * N, -1))
+    pre.reshape(B * N, 3, H * 64)[:, 1:] = qkv_b.reshape(B * N, 3, H * 64)[:, 1:]
+    out = torch.zeros(B * N, H * 64, device=DEV, dtype=torch.bfloat16)
+    hip.attention(pre.to(DEV).bfloat16(), out, B, N, H, 0.0)
+    err = (out.float().cpu().double() - ref).abs().max().item()
+    assert err <= 3e-2, err  # + one extra bf16 rounding of the already-rounded test Q (not present in the fused pipeline)
+
+
+@pytest.mark.parametrize("growth", [3.0, 30.0])
+def test_attention_bf16_prescaled_deferred_rescale_branches(hip, growth):
+    """Late keys whose scores exceed the running reference by less / more than the deferral threshold (rule 26):
+    both the 'keep the reference' and the 'move the reference' paths must give the same softmax."""
+    B, N, H = 1, 300, 1
+    c = 0.125 * 1.4426950408889634
+    qkv = bf16r(rnd(N, 192, seed=3, scale=0.5))
+    qkv[250, 64:128] = bf16r(qkv[5, :64] * growth)   # key 250 spikes for query 5 (and partly for others)
+    qkv[100, 64:128] = bf16r(qkv[40, :64] * growth)
+    ref = attn_ref(qkv, B, N, H, 0.125)
+    pre = qkv.clone()
+    pre[:, :64] = bf16r(pre[:, :64] * c)
+    refp = attn_ref(torch.cat([pre[:, :64] / c, pre[:, 64:]], 1), B, N, H, 0.125)  # exact statement of the pre-rounded problem
+    out = torch.zeros(N, 64, device=DEV, dtype=torch.bfloat16)
+    hip.attention(pre.to(DEV).bfloat16(), out, B, N, H, 0.0)
+    assert (out.float().cpu().double() - refp).abs().max().item() <= 2e-2
+    assert (out.float().cpu().double() - ref).abs().max().item() <= 6e-2
 
 
 def test_attention_bf16_spike_forces_rescale(hip):

@@ -53,7 +53,7 @@ def main():
             gamma = torch.ones(n, device=DEV) if resid else None
             out = torch.randn(m, n, device=DEV) if resid else torch.empty(m, n, device=DEV, dtype=torch.bfloat16)
             row = {}
-            for variant, vname in ((3, "256x256"), (2, "256x128"), (1, "128x128")):
+            for variant, vname in ((1, "128x128-ldsepi"), (28, "128x128-direct")):
                 lib.ufm_debug_set_gemm_variant(variant)
                 med, mn = timeit(lambda: hip.gemm_bf16(A, W, m, n, k, out, bias=bias, act=act, gamma=gamma, res=out if resid else None))
                 row[vname] = dict(ms=med, tflops=2.0 * m * n * k / med / 1e9)
@@ -64,10 +64,16 @@ def main():
         for name, b, n, h in (("enc", 2 * B, 1370, 16), ("info", B, 2738, 12)):
             qkv = torch.randn(b * n, 3 * h * 64, device=DEV).bfloat16()
             out = torch.empty(b * n, h * 64, device=DEV, dtype=torch.bfloat16)
-            med, mn = timeit(lambda: hip.attention(qkv, out, b, n, h, 0.125))
             fl = 4.0 * b * h * n * n * 64
-            res[f"attn_{name}"] = dict(ms=med, tflops=fl / med / 1e9)
-            print("attn", name, round(med, 4), "ms", round(fl / med / 1e9, 1), "TF", flush=True)
+            qkv2 = qkv.clone()
+            qkv2[:, : h * 64] = (qkv[:, : h * 64].float() * (0.125 * 1.4426950408889634)).bfloat16()
+            for sc, vn, dbg in ((0.125, "v1", 0), (0.0, "v2-prescaled", 0), (0.0, "v2-noKVreload(diagnostic)", 1)):
+                src = qkv if sc else qkv2
+                lib.ufm_debug_set_attn_variant(dbg)
+                med, mn = timeit(lambda: hip.attention(src, out, b, n, h, sc))
+                lib.ufm_debug_set_attn_variant(0)
+                res[f"attn_{name}_{vn}"] = dict(ms=med, tflops=fl / med / 1e9)
+                print("attn", name, vn, round(med, 4), "ms", round(fl / med / 1e9, 1), "TF", flush=True)
     if "conv" in args.what:
         zero = torch.zeros(256, device=DEV)
         for name, h, cin, cout, k in (("rcu148", 148, 256, 256, 3), ("rcu74", 74, 256, 256, 3), ("pc1_296", 296, 256, 128, 3), ("pc2_518", 518, 128, 32, 3), ("out148", 148, 256, 256, 1)):

@@ -6,11 +6,11 @@ from ufm_amd import hip
 from tools.kbench import timeit
 lib = hip.lib()
 M = 21920
-for N, resid in ((3072, False), (4096, False)):
-    for variant, vname in ((3, "256x256"), (11, "256x256 all-blocks-tile0 (L2 hits)"), (12, "256x256 no-DMA"), (1, "128x128")):
+for N, resid in ((3072, False), (1024, True)):
+    for variant, vname in ((1, "128x128 LDS-staged epilogue"), (28, "128x128 direct epilogue"), (24, "128x128 no-epilogue")):
         lib.ufm_debug_set_gemm_variant(variant)
         row = []
-        for K in (1024, 4096, 8192):
+        for K in (1024, 4096):
             A = torch.randn(M, K, device="cuda").bfloat16()
             W = (torch.randn(N, K, device="cuda") * K**-0.5).bfloat16()
             out = torch.randn(M, N, device="cuda") if resid else torch.empty(M, N, device="cuda", dtype=torch.bfloat16)

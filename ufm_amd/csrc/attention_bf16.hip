@@ -15,6 +15,8 @@
 //   * K/V: global -> registers -> LDS (register staging, T14): next tile's loads are issued
 //     before this tile's MFMAs, written to the other stage afterwards; one barrier per tile.
 //   * exp2 with scale*log2(e) folded into one FMA per score; ragged tail masked in the last tile.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -210,14 +212,257 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __res
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// v2: the same tiling with the softmax VALU work cut to ~1 exp + 1 add + 1/2 max3 per score.
+// PMC on v1 showed VALU 66 % / MFMA 34 % busy: at head_dim 64 the softmax, not the matrix pipe,
+// is the limiter.  Changes:
+//   * Q arrives PRE-SCALED by softmax_scale*log2(e) (the QKV GEMM epilogue multiplies its Q columns
+//     before the single bf16 rounding, so there is no extra rounding), scores are in log2 units;
+//   * the running reference -m_ref lives in a 16-register block that is the C operand of the first
+//     QK^T MFMA of every key tile: the accumulator comes out as S - m_ref with no zero-init movs and
+//     no per-score subtract/FMA;
+//   * deferred rescale (T13): O, l and m_ref are only touched when some query's tile maximum exceeds
+//     m_ref by more than DEFER_THR log2 units (wave-uniform branch); P then ranges up to 2^DEFER_THR,
+//     which bf16 (relative precision) and the fp32 accumulators absorb.  The first tile always sets
+//     m_ref to its exact maximum (so later tiles can only grow it and nothing underflows).
+// ---------------------------------------------------------------------------------------------
+constexpr float DEFER_THR = 4.0f;
+
+__global__ __launch_bounds__(256, 2) void attn_bf16_kernel_v2(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
+                                                              int N, int H, int debug) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nqb = (N + QB - 1) / QB;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int qblk = lid % nqb, head = (lid / nqb) % H, b = lid / (nqb * H);
+    const int ld = 3 * H * 64;
+    const uint16_t* base = qkv + (size_t)b * N * ld + head * 64;
+    const uint16_t* kp = base + H * 64;
+    const uint16_t* vp = base + 2 * H * 64;
+    const int ql = lane & 31, hh = lane >> 5;
+    const int q = qblk * QB + wave * 32 + ql;
+
+    bf16x8 qf[4];
+    {
+        const uint16_t* qr = base + (size_t)min(q, N - 1) * ld + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qr + 16 * s);
+    }
+    const int srow = tid >> 3, schunk = tid & 7;
+    int k_lds[2], v_lds[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = srow + 32 * i;
+        k_lds[i] = r * 128 + ((schunk ^ ((r >> 1) & 7)) << 4);
+        v_lds[i] = 8192 + r * 128 + ((schunk ^ (((r >> 1) & 1) << 2)) << 4);
+    }
+    u32x4 kreg[2], vreg[2];
+    auto load_tile = [&](int t) {
+        if (debug == 1 && t > 0) return;  // diagnostics: timing without K/V global traffic
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const size_t row = (size_t)min(t * KB + srow + 32 * i, N - 1);
+            kreg[i] = *(const u32x4*)(kp + row * ld + schunk * 8);
+            vreg[i] = *(const u32x4*)(vp + row * ld + schunk * 8);
+        }
+    };
+    auto store_tile = [&](int stage) {
+        char* s = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *(u32x4*)(s + k_lds[i]) = kreg[i];
+            *(u32x4*)(s + v_lds[i]) = vreg[i];
+        }
+    };
+    int k_off[2][4];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int key = kt * 32 + ql;
+            k_off[kt][s] = key * 128 + (((2 * s + hh) ^ ((key >> 1) & 7)) << 4);
+        }
+    const int ti = lane & 15, tq = ti >> 2, tp = ti & 3;
+    const int tdc = 16 * ((lane >> 4) & 1) + 4 * tp;
+    int v_off[2][2][2][2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int row = kt * 32 + 16 * s2 + 4 * hh + 8 * e + tq;
+                    const int dcol = dt * 32 + tdc;
+                    v_off[dt][kt][s2][e] = 8192 + row * 128 + ((((dcol >> 3)) ^ (((row >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1);
+                }
+
+    f32x16 oacc[2], negm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        oacc[0][r] = 0.f;
+        oacc[1][r] = 0.f;
+        negm[r] = 0.f;
+    }
+    float l_run = 0.f;
+
+    const int nt = (N + KB - 1) / KB;
+    // One key tile.  FIRST / LAST are compile-time so the steady-state body carries neither the
+    // reference initialisation nor the ragged-tail selects (hipcc if-converts run-time versions of
+    // those into straight-line code that executes on every tile).
+    auto tile = [&](int t, auto first_c, auto last_c) {
+        constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
+        if (!LAST) load_tile(t + 1);
+        const char* s = smem + (t & 1) * STAGE;
+
+        // all 8 K fragments in flight at once (one exposed LDS latency instead of eight) ...
+        bf16x8 kf[2][4];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) kf[kt][ks] = *(const bf16x8*)(s + k_off[kt][ks]);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 st[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][0], qf[0], negm, 0, 0, 0);
+#pragma unroll
+            for (int ks = 1; ks < 4; ++ks) st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][ks], qf[ks], st[kt], 0, 0, 0);
+        }
+        // ... and the 16 transposed V reads are issued now, behind the QK^T MFMAs: they land while the
+        // softmax runs, so no P.V MFMA waits on LDS.
+        bf16x4 vlo[2][2][2], vhi[2][2][2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    vlo[dt][kt][s2] = tr_read(s + v_off[dt][kt][s2][0]);
+                    vhi[dt][kt][s2] = tr_read(s + v_off[dt][kt][s2][1]);
+                }
+        __builtin_amdgcn_sched_barrier(0);
+        if (LAST) {  // ragged tail: keys >= N
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * KB + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (key >= N) st[kt][r] = NEG_BIG;
+                }
+        }
+        float mx = fmaxf(st[0][0], st[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(st[0][r], st[1][r]));
+        {
+            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        if (FIRST) {  // reference = exact maximum of the first tile (O and l are still zero)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                negm[r] = -mx;
+                st[0][r] -= mx;
+                st[1][r] -= mx;
+            }
+        } else if (__builtin_amdgcn_ballot_w64(mx > DEFER_THR) != 0) {  // rare: move the reference
+            asm volatile("" ::: "memory");  // keep this a real (wave-uniform) branch
+            const float d = fmaxf(mx, 0.f);
+            const float alpha = __builtin_amdgcn_exp2f(-d);
+            l_run *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                negm[r] -= d;
+                st[0][r] -= d;
+                st[1][r] -= d;
+                oacc[0][r] *= alpha;
+                oacc[1][r] *= alpha;
+            }
+        }
+        float lsum = 0.f;
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            unsigned pk[8];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(st[kt][r]);
+                const float p1 = __builtin_amdgcn_exp2f(st[kt][r + 1]);
+                lsum += p0;
+                lsum += p1;
+                pk[r >> 1] = pack_bf16x2(p0, p1);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                u32x4 w = {pk[4 * s2], pk[4 * s2 + 1], pk[4 * s2 + 2], pk[4 * s2 + 3]};
+                pf[kt][s2] = __builtin_bit_cast(bf16x8, w);
+            }
+        }
+        l_run += lsum;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x4 lo = vlo[dt][kt][s2], hi = vhi[dt][kt][s2];
+                    const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][s2], oacc[dt], 0, 0, 0);
+                }
+        if (!LAST) store_tile((t + 1) & 1);
+        __syncthreads();
+    };
+    using T_ = std::integral_constant<bool, true>;
+    using F_ = std::integral_constant<bool, false>;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    if (nt == 1) {
+        tile(0, T_{}, T_{});
+    } else {
+        tile(0, T_{}, F_{});
+        for (int t = 1; t < nt - 1; ++t) tile(t, F_{}, F_{});
+        tile(nt - 1, F_{}, T_{});
+    }
+
+    float l_tot;
+    {
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+        l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    const float inv = 1.0f / l_tot;
+    if (q < N) {
+        uint16_t* orow = out + ((size_t)b * N + q) * (H * 64) + head * 64 + 4 * hh;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 pk = {pack_bf16x2(oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv),
+                            pack_bf16x2(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv)};
+                *(u32x2*)(orow + dt * 32 + 8 * g) = pk;
+            }
+    }
+}
+
 }  // namespace
+
+static int g_attn_debug = 0;
+extern "C" int ufm_debug_set_attn_variant(int v) {
+    g_attn_debug = v;
+    return UFM_OK;
+}
 
 extern "C" int ufm_attention_bf16(const uint16_t* qkv, uint16_t* out, int B, int N, int H, float scale, void* stream) {
     UFM_REQUIRE(qkv && out, "ufm_attention_bf16: null pointer");
     UFM_REQUIRE(B > 0 && N > 0 && H > 0 && (int64_t)((N + QB - 1) / QB) * H * B < (1ll << 31), "ufm_attention_bf16: bad shape B=%d N=%d H=%d", B, N, H);
     UFM_REQUIRE(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 8) == 0, "ufm_attention_bf16: misaligned pointer");
     dim3 grid(((N + QB - 1) / QB) * H * B), block(256);
-    hipLaunchKernelGGL(attn_bf16_kernel, grid, block, 0, (hipStream_t)stream, qkv, out, N, H, scale * 1.44269504088896340736f);
+    if (scale == 0.0f)  // Q pre-scaled by softmax_scale*log2(e): scores already in log2 units
+        hipLaunchKernelGGL(attn_bf16_kernel_v2, grid, block, 0, (hipStream_t)stream, qkv, out, N, H, g_attn_debug);
+    else
+        hipLaunchKernelGGL(attn_bf16_kernel, grid, block, 0, (hipStream_t)stream, qkv, out, N, H, scale * 1.44269504088896340736f);
     UFM_CHECK_LAUNCH("ufm_attention_bf16");
     return UFM_OK;
 }

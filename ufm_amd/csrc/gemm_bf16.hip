@@ -74,6 +74,61 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[4][4], 
 }
 
 
+// LDS-staged epilogue for the 128x128 kernel.  Ablation (tools/ksweep.py) showed the direct epilogue --
+// a wave store touching 16 rows x 32 B -- costs ~50 us of a 190 us QKV GEMM.  Each wave parks its 64x64
+// fp32 tile in its own 16 KiB of the (now idle) staging buffer, 16-byte chunk index XOR (row & 15)
+// (conflict-free for both the accumulator-shaped writes and the row-shaped reads), then every wave
+// instruction moves 4 whole rows: 256-B fp32 / 128-B bf16 contiguous per row, for the residual read
+// (in-place update) and the store alike.  Within a wave LDS ops are in order: no barrier after the writes.
+template <int OUT_BF16>
+__device__ __forceinline__ void epilogue_lds(const GemmArgs& p, f32x4 (&acc)[4][4], char* wave_lds, int row0, int col0,
+                                             int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int nb = col0 + n * 16 + fq * 4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f}, gv = {1.f, 1.f, 1.f, 1.f};
+        if (p.bias) bv = *(const f32x4*)(p.bias + nb);
+        if (p.gamma) gv = *(const f32x4*)(p.gamma + nb);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            f32x4 v = acc[n][m] + bv;
+            if (p.act == UFM_ACT_GELU && OUT_BF16) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = gelu_erf_fast(v[j]);
+            } else if (p.act != UFM_ACT_NONE) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act);
+            }
+            if (p.gamma) v *= gv;
+            const int r = m * 16 + fr;
+            *(f32x4*)(wave_lds + r * 256 + (((n * 4 + fq) ^ (r & 15)) << 4)) = v;
+        }
+    }
+    const int rr = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int pass = 0; pass < 16; ++pass) {
+        const int r = pass * 4 + rr;
+        f32x4 v = *(const f32x4*)(wave_lds + r * 256 + ((c ^ (r & 15)) << 4));
+        const int row = row0 + r;
+        if (row >= p.M) continue;
+        const int nb = col0 + c * 4;
+        if (p.res) {
+            const int rrow = (p.res_row_mod > 0) ? (row % p.res_row_mod) : row;
+            v += *(const f32x4*)(p.res + (size_t)rrow * p.ldres + nb);
+        }
+        const int orow = (p.out_row_group > 0)
+                             ? (row / p.out_row_group) * (p.out_row_group + 1) + 1 + row % p.out_row_group
+                             : row;
+        if (OUT_BF16) {
+            u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            *(u32x2*)((uint16_t*)p.out + (size_t)orow * p.ldo + nb) = pk;
+        } else {
+            *(f32x4*)((float*)p.out + (size_t)orow * p.ldo + nb) = v;
+        }
+    }
+}
+
 template <int OUT_BF16>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
@@ -97,6 +152,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
         gw[i] = p.W + (size_t)(n0 + r) * p.ldw + chunk * 8;
     }
     auto stage = [&](int buf, int kt) {
+        if (p.debug & 2) return;  // ablation (tools/): no DMA
         char* sa = smem + buf * STAGE_BYTES + wave * 4096;
         char* sb = sa + BM * BK * 2;
 #pragma unroll
@@ -146,263 +202,250 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
         }
     }
 
-    epilogue<OUT_BF16>(p, acc, m0 + wr * 64, n0 + wc * 64, fr, fq);
+    if (p.debug & 4) {  // ablation (tools/): no epilogue traffic; keep the accumulators live
+        float keep = 0.f;
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) keep += acc[n][m][0] + acc[n][m][1] + acc[n][m][2] + acc[n][m][3];
+        if (keep == 123.456f) ((float*)p.out)[0] = keep;
+        return;
+    }
+    if (p.debug & 8) {  // A/B hook: the direct (unstaged) epilogue
+        epilogue<OUT_BF16>(p, acc, m0 + wr * 64, n0 + wc * 64, fr, fq);
+        return;
+    }
+    __syncthreads();  // every wave is done reading the staging buffers
+    epilogue_lds<OUT_BF16>(p, acc, smem + wave * 16384, m0 + wr * 64, n0 + wc * 64, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
-// Large-problem kernel: 256x128x64 tile, 8 waves (4 along M x 2 along N, 64x64 each, 2 waves per
-// SIMD), 3-stage LDS ring (144 KiB, one block per CU).  The DMA for K-tile t+2 is issued at the top
-// of iteration t, so two tiles of loads are in flight while tile t is consumed; the only wait in
-// the loop is a COUNTED s_waitcnt vmcnt(6) (= this wave's 6 DMA pieces of tile t+1 may stay in
-// flight) followed by one raw s_barrier per K-tile -- never vmcnt(0), never __syncthreads()
-// (cdna_hip_programming.md "Pipelining across barriers").  RAW: a wave reads stage t%3 only after
-// every wave's vmcnt wait for tile t and the barrier; WAR: stage (t+2)%3 == (t-1)%3 is restaged
-// only after the barrier that follows every wave's last read of tile t-1.
+// Persistent large-GEMM kernel: 256 x BN x 32 tiles (BN = 256 or 128), 8 waves, one block per CU
+// that walks its share of the tiles with the DMA ring running ACROSS tile boundaries.
+//
+// Why (measured on MI355X, tools/ksweep.py + PMC): with one tile per block the K-independent cost
+// (first-load latency of every tile, epilogue with the memory system idle during the main loop and
+// saturated at its end, all CUs in lockstep) is 25-50 us per GEMM -- as much as the K=1024 main
+// loop itself; and waves sat 40-47 % of their time on the DMA wait.  Here:
+//   * K-step 32, NS-stage LDS ring (4 x 32 KiB for BN=256, 6 x 24 KiB for BN=128); the fragments of
+//     K-tile g+1 are read into a second register set while the MFMAs of K-tile g run, so a ring
+//     stage is free as soon as its fragments are in registers and the DMA runs NS K-tiles ahead;
+//   * the flat index g runs over (tile, k) pairs of this block: when the issue cursor reaches the end
+//     of a tile it moves to the block's next tile, so the next tile's first K-tiles are already in
+//     LDS when the epilogue of the current tile finishes (stores are asynchronous);
+//   * one counted s_waitcnt vmcnt + one raw s_barrier per K-tile.  RAW: tile g+1 is read after every
+//     wave's vmcnt wait for it and the barrier.  WAR: stage g%NS is restaged (DMA of g+NS) only after
+//     the barrier of iteration g, which every wave reaches after its lgkmcnt(0) for the fragments of
+//     tile g (read during iteration g-1).  The vmcnt immediate counts only DMA pieces; epilogue
+//     loads/stores that slip into the in-order queue make the wait stricter, never weaker.
+//   * LDS rows are 64 B, chunk XOR g[(row>>2)&3] (conflict-free b128 reads); XCD-aware, grouped tile
+//     order so concurrently running blocks share A and W panels in their XCD's L2.
 // ---------------------------------------------------------------------------------------------
-constexpr int LBM = 256, LBN = 128;
-constexpr int LSTAGE = (LBM + LBN) * BK * 2;  // 48 KiB
-
-template <int OUT_BF16>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_kernel_256x128(GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[3 * LSTAGE];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntn = p.N / LBN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = bid / ntn, tn = bid - tm * ntn;
-    const int m0 = tm * LBM, n0 = tn * LBN;
-    const int nk = p.K / BK;
-
-    const int srow = lane >> 3, slot = lane & 7;
-    const uint16_t* ga[4];
-    const uint16_t* gw[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (wave * 4 + i) * 8 + srow;  // A tile row 0..255
-        const int ar = min(m0 + r, p.M - 1);
-        ga[i] = p.A + (size_t)ar * p.lda + (slot ^ (r & 7)) * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = (wave * 2 + i) * 8 + srow;  // W tile row 0..127
-        gw[i] = p.W + (size_t)(n0 + r) * p.ldw + (slot ^ (r & 7)) * 8;
-    }
-    auto stage = [&](int buf, int kt) {
-        char* sa = smem + buf * LSTAGE + wave * 4096;
-        char* sb = smem + buf * LSTAGE + LBM * BK * 2 + wave * 2048;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(ga[i] + kt * BK), LDS_PTR(sa + i * 1024), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gw[i] + kt * BK), LDS_PTR(sb + i * 1024), 16, 0, 0);
-    };
-
-    const int wr = wave >> 1, wc = wave & 1;
-    const int fr = lane & 15, fq = lane >> 4;
-    int a_off[4], b_off[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        a_off[i] = (wr * 64 + i * 16 + fr) * 128;
-        b_off[i] = LBM * BK * 2 + (wc * 64 + i * 16 + fr) * 128;
-    }
-    const int sw = fr & 7;
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    stage(0, 0);
-    if (nk > 1) stage(1, 1);
-    int cur = 0;  // t % 3
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk)
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) stage(cur == 0 ? 2 : cur - 1, kt + 2);  // (kt+2)%3
-        const char* s = smem + cur * LSTAGE;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int coff = ((kk * 4 + fq) ^ sw) * 16;
-            bf16x8 a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] = *(const bf16x8*)(s + a_off[i] + coff);
-                b[i] = *(const bf16x8*)(s + b_off[i] + coff);
-            }
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[n], a[m], acc[n][m], 0, 0, 0);
-        }
-        cur = cur == 2 ? 0 : cur + 1;
-    }
-    epilogue<OUT_BF16>(p, acc, m0 + wr * 64, n0 + wc * 64, fr, fq);
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// 256x256x32 kernel for the large GEMMs.  PMC profiling of the kernels above showed waves parked
-// 47 % of the time on the DMA wait: the global->LDS fill rate (~30-70 GB/s per CU), not the matrix
-// pipe, bounds a tile whose operands are streamed through LDS.  A 256x256 tile needs half the fill
-// bytes per FLOP of 256x128 and a quarter of 128x128.
-//   * 8 waves as 2 (M) x 4 (N): 128x64 per wave = 8x4 MFMA tiles, 128 accumulator VGPRs.
-//   * K-step 32 (64-byte LDS rows, chunk XOR g[(row>>2)&3], g={0,2,3,1}: conflict-free b128 reads),
-//     4-stage ring of 32 KiB: tiles t+1..t+3 are in flight while tile t is consumed; the loop waits
-//     with a counted vmcnt(8) (this wave's 4+4 DMA pieces of the next two tiles stay in flight) and
-//     one raw s_barrier per K-step.
-//   * grouped rasterization: 32 consecutive logical tiles (one XCD's worth) cover 4 M-panels x 8
-//     N-panels, so every A panel is reused 8x and every W panel 4x out of that XCD's L2.
-// ---------------------------------------------------------------------------------------------
-constexpr int HBM_ = 256, HBN = 256, HBK = 32;
-constexpr int HSTAGE = (HBM_ + HBN) * HBK * 2;  // 32 KiB
+constexpr int PBM = 256, PBK = 32;
 constexpr int GROUP_M = 4;
 
 __device__ __forceinline__ int swz64(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
 
-template <int OUT_BF16>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_kernel_256x256(GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * HSTAGE];
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BN, int OUT_BF16>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_persistent(GemmArgs p) {
+    constexpr int NS = BN == 256 ? 4 : 6;            // ring stages
+    constexpr int STAGE = (PBM + BN) * PBK * 2;      // 32 / 24 KiB
+    constexpr int WN = BN / 64, WM = 8 / WN;         // 2x4 or 4x2 waves
+    constexpr int TM = (PBM / WM) / 16;              // 8 or 4 row tiles per wave
+    constexpr int PA = 2, PW = BN / 128;             // DMA pieces (16 rows x 64 B) per wave per K-tile
+    constexpr int P = PA + PW;
+    __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
+
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntn = p.N / HBN, ntm = (p.M + HBM_ - 1) / HBM_;
-    // grouped rasterization on top of the XCD chunking
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int per_group = GROUP_M * ntn;
-    const int g = lid / per_group, in_g = lid - g * per_group;
-    const int gm = min(GROUP_M, ntm - g * GROUP_M);  // rows in this (possibly last, shorter) group
-    const int tm = g * GROUP_M + in_g % gm, tn = in_g / gm;
-    const int m0 = (p.debug == 1) ? 0 : tm * HBM_, n0 = (p.debug == 1) ? 0 : tn * HBN;
-    const int nk = p.K / HBK;
+    const int ntn = p.N / BN, ntm = (p.M + PBM - 1) / PBM, ntiles = ntm * ntn;
+    const int nk = p.K / PBK;
+    const int nblk = gridDim.x;
+    const int bslot = xcd_remap(blockIdx.x, nblk);
+    const int my_tiles = (ntiles - bslot + nblk - 1) / nblk;  // tiles bslot, bslot+nblk, ...
+    const int G = my_tiles * nk;                              // flat (tile, k) iterations of this block
 
-    // DMA pieces: 1 KiB = 16 rows of 64 B.  wave w: A rows [32w, 32w+32), W rows [32w, 32w+32).
+    auto tile_origin = [&](int j, int& m0, int& n0) {  // j-th tile of this block -> grouped rasterization
+        const int lid = bslot + j * nblk;
+        const int per_group = GROUP_M * ntn;
+        const int g = lid / per_group, in_g = lid - g * per_group;
+        const int gm = min(GROUP_M, ntm - g * GROUP_M);
+        m0 = (p.debug == 1) ? 0 : (g * GROUP_M + in_g % gm) * PBM;
+        n0 = (p.debug == 1) ? 0 : (in_g / gm) * BN;
+    };
+
+    // ---- DMA issue cursor ----
     const int srow = lane >> 2, slot = lane & 3;
-    const uint16_t* ga[2];
-    const uint16_t* gw[2];
+    int ia_off[PA], iw_off[PW];  // element offsets of this lane's source rows for the tile being issued
+    int i_tile = 0, i_kt = 0;
+    auto set_issue_tile = [&](int j) {
+        int m0, n0;
+        tile_origin(j, m0, n0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = wave * 32 + i * 16 + srow;
-        const int ar = min(m0 + r, p.M - 1);
-        ga[i] = p.A + (size_t)ar * p.lda + (slot ^ swz64(r)) * 8;
-        gw[i] = p.W + (size_t)(n0 + r) * p.ldw + (slot ^ swz64(r)) * 8;
-    }
-    auto stage = [&](int buf, int kt) {
-        if (p.debug == 2) return;
-        char* sa = smem + buf * HSTAGE + wave * 2048;
-        char* sb = sa + HBM_ * HBK * 2;
+        for (int i = 0; i < PA; ++i) {
+            const int r = wave * 32 + i * 16 + srow;
+            ia_off[i] = min(m0 + r, p.M - 1) * p.lda + (slot ^ swz64(r)) * 8;
+        }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(ga[i] + kt * HBK), LDS_PTR(sa + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gw[i] + kt * HBK), LDS_PTR(sb + i * 1024), 16, 0, 0);
+        for (int i = 0; i < PW; ++i) {
+            const int r = wave * (16 * PW) + i * 16 + srow;
+            iw_off[i] = (n0 + r) * p.ldw + (slot ^ swz64(r)) * 8;
+        }
+    };
+    auto issue = [&](int g) {  // DMA of flat iteration g (always == the cursor position)
+        if (p.debug != 2) {
+            char* sa = smem + (g % NS) * STAGE + wave * 2048;
+            char* sb = smem + (g % NS) * STAGE + PBM * PBK * 2 + wave * (1024 * PW);
+#pragma unroll
+            for (int i = 0; i < PA; ++i)
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(p.A + ia_off[i] + i_kt * PBK), LDS_PTR(sa + i * 1024), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < PW; ++i)
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(p.W + iw_off[i] + i_kt * PBK), LDS_PTR(sb + i * 1024), 16, 0, 0);
+        }
+        if (++i_kt == nk) {
+            i_kt = 0;
+            if (++i_tile < my_tiles) set_issue_tile(i_tile);
         }
     };
 
-    const int wr = wave >> 2, wc = wave & 3;  // 2 x 4
+    // ---- fragment offsets ----
+    const int wr = wave / WN, wc = wave % WN;
     const int fr = lane & 15, fq = lane >> 4;
-    int a_off[8], b_off[4];
+    int a_off[TM], b_off[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int r = wr * 128 + i * 16 + fr;
+    for (int i = 0; i < TM; ++i) {
+        const int r = wr * (TM * 16) + i * 16 + fr;
         a_off[i] = r * 64 + ((fq ^ swz64(r)) << 4);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = wc * 64 + i * 16 + fr;
-        b_off[i] = HBM_ * HBK * 2 + r * 64 + ((fq ^ swz64(r)) << 4);
+        b_off[i] = PBM * PBK * 2 + r * 64 + ((fq ^ swz64(r)) << 4);
     }
 
-    f32x4 acc[4][8];
+    f32x4 acc[4][TM];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int n = 0; n < 4; ++n)
+        for (int n = 0; n < 4; ++n)
 #pragma unroll
-        for (int m = 0; m < 8; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // Software pipeline inside each wave: the fragments of K-tile t+1 are read from LDS while the
-    // MFMAs of K-tile t run (two named register sets, statically indexed -- rule 20), so LDS latency
-    // never sits between a barrier and the first MFMA.  Iteration kt:
-    //   wait(tile kt+1 landed) ; barrier ; DMA(tile kt+4) ; ds_read(tile kt+1) || MFMA(tile kt)
-    // Ring of 4 stages: the barrier of iteration kt follows every wave's ds_reads of tile kt (issued in
-    // iteration kt-1 and consumed by its own MFMAs before it reaches this barrier?  no -- they are only
-    // ISSUED; a wave passes lgkmcnt(0) for them before its MFMAs of iteration kt, i.e. before the
-    // barrier of iteration kt+1), so the stage of tile kt is restaged at iteration kt+1 at the earliest:
-    // DMA(tile kt+4) at iteration kt targets stage (kt+4)&3 == kt&3 ... which tile kt's reads may still
-    // be using.  Therefore the DMA look-ahead is 3 tiles (stage (kt+3)&3 == (kt-1)&3, whose reads were
-    // waited for before the MFMAs of iteration kt-1, before this barrier).
-    stage(0, 0);
-    if (nk > 1) stage(1, 1);
-    if (nk > 2) stage(2, 2);
-    bf16x8 a0[8], b0[4], a1[8], b1[4];
-    auto read_frags = [&](bf16x8 (&a)[8], bf16x8 (&b)[4], int kt) {
-        const char* s = smem + (kt & 3) * HSTAGE;
+            for (int m = 0; m < TM; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    bf16x8 a0[TM], b0[4], a1[TM], b1[4];
+    auto read_frags = [&](bf16x8 (&a)[TM], bf16x8 (&b)[4], int g) {
+        const char* s = smem + (g % NS) * STAGE;
 #pragma unroll
         for (int i = 0; i < 4; ++i) b[i] = *(const bf16x8*)(s + b_off[i]);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) a[i] = *(const bf16x8*)(s + a_off[i]);
+        for (int i = 0; i < TM; ++i) a[i] = *(const bf16x8*)(s + a_off[i]);
     };
-    auto wait_tile = [&](int kt) {  // this wave's DMA pieces of tile kt have landed (later tiles may be in flight)
-        const int younger = min(nk - 1, kt + 2) - kt;  // tiles issued after kt so far: kt+1, kt+2 (kt+3 is issued after the barrier)
-        if (younger >= 2)
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (younger == 1)
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    auto mfma_all = [&](bf16x8 (&a)[8], bf16x8 (&b)[4]) {
+    auto mfma_all = [&](bf16x8 (&a)[TM], bf16x8 (&b)[4]) {
 #pragma unroll
-        for (int m = 0; m < 8; ++m)
+        for (int m = 0; m < TM; ++m)
 #pragma unroll
             for (int n = 0; n < 4; ++n)
                 acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[n], a[m], acc[n][m], 0, 0, 0);
     };
-    wait_tile(0);
-    __builtin_amdgcn_s_barrier();
-    read_frags(a0, b0, 0);
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    for (int kt = 0; kt < nk; kt += 2) {
-        // ---- even half: MFMA(kt) from set 0, prefetch set 1 <- tile kt+1 ----
-        if (kt + 1 < nk) {
-            wait_tile(kt + 1);
-            __builtin_amdgcn_s_barrier();
-            if (kt + 3 < nk) stage((kt + 3) & 3, kt + 3);
-            read_frags(a1, b1, kt + 1);
+    // wait until this wave's DMA pieces of flat iteration x have landed; `issued` = highest index issued so far
+    auto wait_landed = [&](int x, int issued) {
+        const int younger = issued - x;  // 0 .. NS-1 tiles issued after x
+        if (younger >= NS - 1) wait_vmcnt<P*(NS - 1)>();
+        else if (younger == NS - 2) wait_vmcnt<P*(NS - 2)>();
+        else if (younger == 2 && NS > 4) wait_vmcnt<P * 2>();
+        else if (younger == 3 && NS > 5) wait_vmcnt<P * 3>();
+        else if (younger == 1) wait_vmcnt<P>();
+        else wait_vmcnt<0>();
+    };
+
+    int c_tile = 0, c_kt = 0;  // compute cursor
+    auto finish_kt = [&]() {   // after the MFMAs of one K-tile: epilogue at the end of a tile
+        if (++c_kt == nk) {
+            int m0, n0;
+            tile_origin(c_tile, m0, n0);
+            if (p.debug == 1) tile_origin(c_tile, m0, n0);
+#pragma unroll
+            for (int h = 0; h < TM / 4; ++h) {
+                f32x4 part[4][4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) part[n][m] = acc[n][h * 4 + m];
+                epilogue<OUT_BF16>(p, part, m0 + wr * (TM * 16) + h * 64, n0 + wc * 64, fr, fq);
+            }
+            zero_acc();
+            c_kt = 0;
+            ++c_tile;
         }
-        mfma_all(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);   // keep the wait BELOW the MFMAs (the scheduler otherwise hoists it)
-        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): set 1 landed long ago; compiler-visible so no wait is re-inserted at the loop head
-        if (kt + 1 >= nk) break;
-        // ---- odd half: MFMA(kt+1) from set 1, prefetch set 0 <- tile kt+2 ----
-        if (kt + 2 < nk) {
-            wait_tile(kt + 2);
-            __builtin_amdgcn_s_barrier();
-            if (kt + 4 < nk) stage((kt + 4) & 3, kt + 4);
-            read_frags(a0, b0, kt + 2);
+    };
+
+    if (G == 0) return;
+    zero_acc();
+    set_issue_tile(0);
+    int issued = -1;
+    constexpr bool DB = (BN == 128);  // second fragment register set only where 128 accumulators leave room
+    if constexpr (DB) {
+        for (int g = 0; g < NS && g < G; ++g) {
+            issue(g);
+            issued = g;
         }
-        mfma_all(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-    }
-    // epilogue in two 64-row halves (reuses the 64x64 epilogue)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        f32x4 part[4][4];
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) part[n][m] = acc[n][h * 4 + m];
-        epilogue<OUT_BF16>(p, part, m0 + wr * 128 + h * 64, n0 + wc * 64, fr, fq);
+        wait_landed(0, issued);
+        __builtin_amdgcn_s_barrier();
+        read_frags(a0, b0, 0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+        for (int g = 0; g < G; g += 2) {
+            // ---- even: MFMA(g) from set 0 ; prefetch set 1 <- g+1 ----
+            if (g + 1 < G) {
+                wait_landed(g + 1, issued);
+                __builtin_amdgcn_s_barrier();
+                if (issued + 1 < G) issue(++issued);  // into stage g % NS (fragments of g are in registers)
+                read_frags(a1, b1, g + 1);
+            }
+            mfma_all(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            finish_kt();
+            if (g + 1 >= G) break;
+            // ---- odd: MFMA(g+1) from set 1 ; prefetch set 0 <- g+2 ----
+            if (g + 2 < G) {
+                wait_landed(g + 2, issued);
+                __builtin_amdgcn_s_barrier();
+                if (issued + 1 < G) issue(++issued);
+                read_frags(a0, b0, g + 2);
+            }
+            mfma_all(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            finish_kt();
+        }
+    } else {
+        // single fragment set: stage (g-1)%NS is free after the barrier of iteration g (its fragments were
+        // waited for before the MFMAs of iteration g-1), so the DMA runs NS-1 K-tiles ahead.
+        for (int g = 0; g < NS - 1 && g < G; ++g) {
+            issue(g);
+            issued = g;
+        }
+        for (int g = 0; g < G; ++g) {
+            wait_landed(g, issued);
+            __builtin_amdgcn_s_barrier();
+            if (issued + 1 < G) issue(++issued);
+            read_frags(a0, b0, g);
+            mfma_all(a0, b0);
+            finish_kt();
+        }
     }
 }
+
 
 }  // namespace
 
 static int g_force_small = 0;
-// test/tuning hook: 0 = auto, 1 = 128x128 kernel, 2 = 256x128 kernel, 3 = 256x256 kernel (A/B timing in one process)
+// test/tuning hook: 0 = auto, 1 = 128x128 kernel, 2 = persistent 256x128, 3 = persistent 256x256; 11/12 = diagnostics
 extern "C" int ufm_debug_set_gemm_variant(int force_small) {
     g_force_small = force_small;
     return UFM_OK;
@@ -421,24 +464,33 @@ extern "C" int ufm_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int 
     UFM_REQUIRE(ldo % 4 == 0 && ldo >= N && (!res || (ldres % 4 == 0 && ldres >= N)), "ufm_gemm_bf16: bad ldo/ldres");
     UFM_REQUIRE(out_dtype == UFM_F32 || out_dtype == UFM_BF16, "ufm_gemm_bf16: bad out_dtype %d", out_dtype);
     UFM_REQUIRE((size_t)M * (size_t)(lda > ldo ? lda : ldo) < (1ull << 40), "ufm_gemm_bf16: problem too large");
-    GemmArgs p{A, W, bias, gamma, res, out, lda, ldw, M, N, K, act, ldres, res_row_mod, ldo, out_row_group, g_force_small >= 10 ? g_force_small - 10 : 0};
-    // big tile when it fills the chip (>= 256 tiles of 256x128), else the 128x128 kernel (2 blocks/CU)
-    const int big_tiles = ((M + LBM - 1) / LBM) * (N / LBN);
-    const int huge_tiles = (N % HBN == 0) ? ((M + HBM_ - 1) / HBM_) * (N / HBN) : 0;
-    // 256x256 pays off only when its wave quantization is good: tiles / (rounds * 256 CUs) >= 0.88
-    const bool huge_ok = huge_tiles >= 192 && huge_tiles * 100 >= 88 * (((huge_tiles + 255) / 256) * 256);
-    if ((huge_ok && g_force_small == 0) || (huge_tiles > 0 && (g_force_small == 3 || g_force_small >= 10))) {
-        dim3 grid(huge_tiles), block(512);
+    GemmArgs p{A, W, bias, gamma, res, out, lda, ldw, M, N, K, act, ldres, res_row_mod, ldo, out_row_group, g_force_small >= 20 ? g_force_small - 20 : (g_force_small >= 10 ? g_force_small - 10 : 0)};
+    // Kernel choice.  The persistent 256xBN kernels (DMA ring across tiles) are kept as opt-in variants 2/3:
+    // they are correct (tests/test_kernels_gpu.py) but measured 5-30 % SLOWER than the 128x128 kernel on the
+    // UFM shapes -- two independent co-resident blocks per CU overlap DMA waits, epilogues and MFMA phases
+    // better than a single hand-pipelined block.
+    constexpr int NCU = 256;
+    const int ntm256 = (M + PBM - 1) / PBM;
+    const int t256 = (N % 256 == 0) ? ntm256 * (N / 256) : 0;
+    const int t128 = ntm256 * (N / 128);
+    int variant = g_force_small >= 20 ? 1 : (g_force_small >= 10 ? 3 : g_force_small);  // 0 auto, 1 = 128x128, 2 = persistent BN=128, 3 = persistent BN=256
+    if (variant == 0) variant = 1;  // measured (tools/kbench.py, profiles/r01): 128x128 with two co-resident blocks per CU and
+                                    // the LDS-staged epilogue beats both persistent shapes on every UFM GEMM at B=8
+    if (variant == 3 && t256 == 0) variant = 2;
+    const bool fits32 = (long long)M * lda < (1ll << 31) && (long long)N * ldw < (1ll << 31);
+    if (!fits32) variant = 1;
+    if (variant == 3) {
+        dim3 grid(t256 < NCU ? t256 : NCU), block(512);
         if (out_dtype == UFM_BF16)
-            hipLaunchKernelGGL(gemm_bf16_kernel_256x256<1>, grid, block, 0, (hipStream_t)stream, p);
+            hipLaunchKernelGGL((gemm_bf16_persistent<256, 1>), grid, block, 0, (hipStream_t)stream, p);
         else
-            hipLaunchKernelGGL(gemm_bf16_kernel_256x256<0>, grid, block, 0, (hipStream_t)stream, p);
-    } else if (big_tiles >= 256 && g_force_small != 1) {
-        dim3 grid(big_tiles), block(512);
+            hipLaunchKernelGGL((gemm_bf16_persistent<256, 0>), grid, block, 0, (hipStream_t)stream, p);
+    } else if (variant == 2) {
+        dim3 grid(t128 < NCU ? t128 : NCU), block(512);
         if (out_dtype == UFM_BF16)
-            hipLaunchKernelGGL(gemm_bf16_kernel_256x128<1>, grid, block, 0, (hipStream_t)stream, p);
+            hipLaunchKernelGGL((gemm_bf16_persistent<128, 1>), grid, block, 0, (hipStream_t)stream, p);
         else
-            hipLaunchKernelGGL(gemm_bf16_kernel_256x128<0>, grid, block, 0, (hipStream_t)stream, p);
+            hipLaunchKernelGGL((gemm_bf16_persistent<128, 0>), grid, block, 0, (hipStream_t)stream, p);
     } else {
         const int ntm = (M + BM - 1) / BM, ntn = N / BN;
         dim3 grid(ntm * ntn), block(256);

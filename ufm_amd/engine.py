@@ -48,6 +48,9 @@ class _Lin:
         self.b = _f32(lin.bias, dev) if lin.bias is not None else None
 
 
+LOG2E = 1.4426950408889634
+
+
 class _Blk:
     def __init__(self, blk, dev, wdt):
         self.n1w, self.n1b = _f32(blk.norm1.weight, dev), _f32(blk.norm1.bias, dev)
@@ -56,6 +59,12 @@ class _Blk:
         self.fc1, self.fc2 = _Lin(blk.mlp.fc1, dev, wdt), _Lin(blk.mlp.fc2, dev, wdt)
         self.ls1 = _f32(blk.ls1.gamma, dev) if hasattr(blk.ls1, "gamma") else None
         self.ls2 = _f32(blk.ls2.gamma, dev) if hasattr(blk.ls2, "gamma") else None
+        # fast mode: the QKV epilogue scales the Q columns by softmax_scale*log2(e) BEFORE the bf16 rounding,
+        # so the attention kernel works in the log2 domain with no per-score multiply and no extra rounding
+        d = self.qkv.n // 3
+        self.qscale = None
+        if wdt == torch.bfloat16:
+            self.qscale = torch.cat([torch.full((d,), 0.125 * LOG2E), torch.ones(2 * d)]).to(device=dev, dtype=torch.float32)
 
 
 def _split_bf16(w: torch.Tensor) -> torch.Tensor:
@@ -274,8 +283,8 @@ class Engine:
         hid = self.buf("hid", (M, blocks[0].fc1.n), self.adt)
         for i, w in enumerate(blocks):
             hip.layernorm(x, D, None, M, D, w.n1w, w.n1b, 1e-6, xn)
-            self.linear(xn, w.qkv, M, qkv)
-            hip.attention(qkv, ao, Bseq, N, heads, 0.125)
+            self.linear(xn, w.qkv, M, qkv, gamma=w.qscale)
+            hip.attention(qkv, ao, Bseq, N, heads, 0.0 if w.qscale is not None else 0.125)
             self.linear(ao, w.proj, M, x, gamma=w.ls1, res=x)
             hip.layernorm(x, D, None, M, D, w.n2w, w.n2b, 1e-6, xn)
             self.linear(xn, w.fc1, M, hid, act=hip.ACT_GELU)
