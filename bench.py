@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--numerics", default="fast", choices=["fast", "parity"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--micro-batches", type=int, default=2, help="concurrent micro-batches (HIP streams) per GPU; 1 = single stream")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -88,6 +89,7 @@ def main():
     model = ufm_amd.UniFlowMatchConfidence(**cfg).eval()
     init_weights_(model, seed=0)  # deterministic CPU RNG: identical weights on every rank
     model = model.to(dev).set_numerics(args.numerics)
+    model.engine().micro_batches = args.micro_batches
 
     B = args.batch
     g = torch.Generator().manual_seed(1234 + rank)  # each rank owns its own slice of the global batch
@@ -149,6 +151,7 @@ def main():
             "resolution": res,
             "numerics": f"{args.numerics}: " + ("bf16 MFMA trunk (fp32 accumulate/residual/LN/softmax stats), DPT heads in bf16x3 split precision (~2^-17 rel., fp32 accumulate)" if args.numerics == "fast" else "fp32 MFMA everywhere"),
             "parallelism": f"dp{world} (pair-batch split, RCCL all_gather of results)",
+            "micro_batches_per_gpu": args.micro_batches,
         },
     }
 

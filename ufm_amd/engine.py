@@ -23,6 +23,7 @@ Numerics modes
 
 from __future__ import annotations
 
+import threading
 from typing import Any, Dict, List, Optional, Tuple
 
 import torch
@@ -136,6 +137,9 @@ class Engine:
         self._bufs: Dict[str, torch.Tensor] = {}
         self._tables: Dict[Any, Any] = {}
         self._packed_key = None
+        self._tls = threading.local()  # .ns = workspace namespace of the micro-batch this thread is running
+        self.micro_batches = 2  # >1: the batch is split into micro-batches that run concurrently on separate HIP streams
+        self._streams: List[torch.cuda.Stream] = []
 
     # ------------------------------------------------------------------ packing
     def _pack(self) -> None:
@@ -196,6 +200,7 @@ class Engine:
 
     # ------------------------------------------------------------------ small helpers
     def buf(self, name: str, shape: Tuple[int, ...], dtype=torch.float32) -> torch.Tensor:
+        name = getattr(self._tls, "ns", "") + name
         t = self._bufs.get(name)
         if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
             t = torch.empty(shape, device=self.dev, dtype=dtype)
@@ -371,8 +376,80 @@ class Engine:
     @torch.no_grad()
     def forward(self, src, tgt, *, layout: int, scale3, shift3, H: int, W: int, Hs: int, Ws: int, Ht: int, Wt: int) -> Dict[str, Any]:
         """src/tgt: device images (uint8 or float32, BHWC layout=0 / BCHW layout=1) of sizes
-        (Hs,Ws)/(Ht,Wt); (H,W) is the network resolution.  Returns network-resolution outputs."""
+        (Hs,Ws)/(Ht,Wt); (H,W) is the network resolution.  Returns network-resolution outputs.
+
+        Pairs are independent, so with ``micro_batches`` > 1 the batch is split into contiguous
+        micro-batches that run CONCURRENTLY on separate HIP streams (one host thread each, own
+        workspace): one micro-batch's HBM-bound phases and wave-quantization tails overlap the other's
+        MFMA phases.  Results are identical to the single-stream run (each pair's arithmetic does not
+        depend on its batch neighbours)."""
         self._pack()
+        B = src.shape[0]
+        nmb = self.micro_batches if (B >= 2 * self.micro_batches and hip.TIMER is None) else 1
+        if nmb == 1:
+            self._tls.ns = ""
+            return self._forward_images(src, tgt, layout, scale3, shift3, H, W, Hs, Ws, Ht, Wt)
+        bounds = [(i * B) // nmb for i in range(nmb + 1)]
+        gh, gw = H // self.P, W // self.P
+        self._pos_tables(H, W)  # shared read-only tables are built here, before the workers start
+        self._view_pe_table(gh * gw)
+        for i in range(nmb):
+            self._index_tables(bounds[i + 1] - bounds[i], gh * gw)
+        while len(self._streams) < nmb:
+            self._streams.append(torch.cuda.Stream(device=self.dev))
+        cur = torch.cuda.current_stream(self.dev)
+        results: List[Any] = [None] * nmb
+        errors: List[BaseException] = []
+
+        def work(i: int):
+            try:
+                with torch.cuda.device(self.dev), torch.cuda.stream(self._streams[i]):
+                    self._tls.ns = f"mb{i}/"
+                    lo, hi = bounds[i], bounds[i + 1]
+                    results[i] = self._forward_images(src[lo:hi], tgt[lo:hi], layout, scale3, shift3, H, W, Hs, Ws, Ht, Wt)
+            except BaseException as exc:  # surfaced on the caller's thread
+                errors.append(exc)
+
+        for s in self._streams[:nmb]:
+            s.wait_stream(cur)  # inputs produced on the caller's stream
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(1, nmb)]
+        for t in threads:
+            t.start()
+        work(0)
+        for t in threads:
+            t.join()
+        for s in self._streams[:nmb]:
+            cur.wait_stream(s)
+        if errors:
+            raise errors[0]
+        return self._merge(results)
+
+    def _merge(self, parts: List[Dict[str, Any]]) -> Dict[str, Any]:
+        """Concatenate micro-batch results along the pair dimension (small planar outputs only)."""
+        def cat(vals):
+            if vals[0] is None:
+                return None
+            if isinstance(vals[0], torch.Tensor):
+                cur = torch.cuda.current_stream(self.dev)
+                for v in vals:
+                    v.record_stream(cur)  # allocated on a side stream, consumed here on the caller's stream
+                return torch.cat(vals, dim=0)
+            return vals[0]
+
+        out: Dict[str, Any] = {}
+        for tag in parts[0]:
+            if tag == "refine":
+                r = {k: cat([p[tag][k] for p in parts]) for k in parts[0][tag] if k != "feats"}
+                f = [p[tag]["feats"] for p in parts]  # each (2b, C, H, W): [view-1 block | view-2 block]
+                for x in f:
+                    x.record_stream(torch.cuda.current_stream(self.dev))
+                r["feats"] = torch.cat([x[: x.shape[0] // 2] for x in f] + [x[x.shape[0] // 2 :] for x in f], dim=0)
+                out[tag] = r
+            else:
+                out[tag] = {name: {k: cat([p[tag][name][k] for p in parts]) for k in parts[0][tag][name]} for name in parts[0][tag]}
+        return out
+
+    def _forward_images(self, src, tgt, layout, scale3, shift3, H, W, Hs, Ws, Ht, Wt) -> Dict[str, Any]:
         B = src.shape[0]
         B2 = 2 * B
         gh, gw = H // self.P, W // self.P
