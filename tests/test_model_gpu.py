@@ -176,3 +176,88 @@ def test_ufm_base_full_size_parity(env):
     mean_abs = (o.flow.flow_output - pf.flow.flow_output.cpu()).abs().mean().item()
     print(f"UFM-Base 518 fast (bf16) mode: flow max-abs {df2:.3g} mean-abs {mean_abs:.3g} (range {mx:.3g}), mask {dm2:.3g}")
     assert df2 <= 0.05 * mx and dm2 <= 0.05, (df2, dm2, mx)
+
+
+def test_config4_ufm_refine_full_size_parity(env):
+    """BASELINE config 4: UFM-Refine (UniFlowMatchClassificationRefinement) 518x518, B=1: the whole path incl.
+    the patch-MLP feature head and the fused bicubic-gather/softmax refinement vs the fp32 CPU oracle."""
+    ufm_amd, R = env
+    oracle = R.UFMRef(**R.make_config(refine=True, enc_indices=[5, 23])).eval()
+    R.init_weights_(oracle, 0)
+    prod = ufm_amd.UniFlowMatchClassificationRefinement(**ufm_amd.ufm_refine_config()).eval()
+    prod.load_state_dict(oracle.state_dict(), strict=True)
+    prod = prod.to(DEV)
+    src, tgt = u8((1, 518, 518, 3), 77), u8((1, 518, 518, 3), 78)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    o = oracle.predict_correspondences_batched(src, tgt)
+    p = prod.set_numerics("parity").predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
+    df, dm, mx = compare(o, p)
+    print(f"UFM-Refine 518 parity mode: flow max-abs {df:.3g} px (range {mx:.3g}), mask {dm:.3g}")
+    assert df <= 1e-3 and dm <= 1e-3, (df, dm, mx)
+    # lower-level forward exposes the refinement bundle (ufm.py:1001-1007)
+    a = torch.randn(1, 3, 518, 518, generator=torch.Generator().manual_seed(5))
+    v = lambda t: {"img": t.to(DEV), "symmetrized": False, "data_norm_type": "dinov2"}  # noqa: E731
+    r = prod(v(a), v(a.flip(-1)))
+    cr = r.classification_refinement
+    assert cr.residual.shape == (1, 2, 518, 518) and cr.log_softmax.shape == (1, 518, 518, 5, 5)
+    assert cr.feature_map_0.shape == (1, 16, 518, 518) and cr.feature_map_1.shape == (1, 16, 518, 518)
+    assert torch.allclose(cr.log_softmax.exp().sum(dim=(-1, -2)), torch.ones(1, 518, 518, device=DEV), atol=1e-4)
+    assert torch.equal(cr.regression_flow_output, r.flow.flow_output)  # reference quirk: it is the REFINED flow
+
+
+def test_config5_1036_long_sequence_properties(env):
+    """BASELINE config 5: UFM-Base at 1036x1036 (5477 tokens/image, 10952 joint tokens; pos-embed bicubically
+    interpolated 37->74).  The fp32 CPU oracle would need minutes here, so the check is property-based: the bf16
+    and the exact-fp32 HIP paths (different kernels for every contraction) agree, results are finite,
+    deterministic, and independent of batch composition."""
+    ufm_amd, R = env
+    prod = ufm_amd.UniFlowMatchConfidence(**ufm_amd.ufm_base_config(resolution_wh=(1036, 1036))).eval()
+    ufm_amd.modules.init_weights_(prod, 0)
+    prod = prod.to(DEV)
+    src, tgt = u8((2, 1036, 1036, 3), 5).to(DEV), u8((2, 1036, 1036, 3), 6).to(DEV)
+    fast = prod.set_numerics("fast").predict_correspondences_batched(src, tgt)
+    f1 = fast.flow.flow_output.clone()
+    assert f1.shape == (2, 2, 1036, 1036) and torch.isfinite(f1).all() and torch.isfinite(fast.covisibility.mask).all()
+    again = prod.predict_correspondences_batched(src, tgt).flow.flow_output
+    assert torch.equal(f1, again)
+    single = prod.predict_correspondences_batched(src[1:], tgt[1:]).flow.flow_output
+    assert torch.equal(f1[1:], single)
+    par = prod.set_numerics("parity").predict_correspondences_batched(src[:1], tgt[:1])
+    rng = par.flow.flow_output.abs().max().item()
+    d = (par.flow.flow_output - f1[:1]).abs().max().item()
+    dm = (par.covisibility.mask - fast.covisibility.mask[:1]).abs().max().item()
+    print(f"1036x1036: fast-vs-parity flow max-abs {d:.3g} (range {rng:.3g}), mask {dm:.3g}")
+    assert d <= 0.05 * rng and dm <= 0.05
+
+
+def test_config1_shapes_unequal_sizes_multi_resolution(env):
+    """BASELINE config 1 plumbing shapes (examples/image_pairs: 1080x1080, 1080x607 RGB, source and target of
+    different size) on synthetic content, multi-resolution selection, tiny weights; vs the oracle in parity mode."""
+    ufm_amd, R = env
+
+    def cfg(mod):
+        c = mod.ufm_tiny_config(resolution_wh=(56, 56))
+        c["inference_resolution"] = [(56, 42), (42, 56), (56, 56)]
+        return c
+
+    oracle, prod = build_pair(env, cfg_fn=cfg)
+    prod.set_numerics("parity")
+    for s_hw, t_hw in (((607, 1080), (580, 1080)), ((1080, 1080), (810, 1080)), ((1080, 607), (1080, 607))):
+        src, tgt = u8((s_hw[0], s_hw[1], 3), 11), u8((t_hw[0], t_hw[1], 3), 12)
+        o = oracle.predict_correspondences_batched(src, tgt)
+        p = prod.predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
+        assert p.flow.flow_output.shape == (1, 2, s_hw[0], s_hw[1])
+        df, dm, mx = compare(o, p)
+        # un-mapping multiplies network-resolution flow by ~20x (56 -> 1080 px): scale the 1e-3 gate accordingly
+        assert df <= 2e-3 * max(s_hw) / 56 and dm <= 1e-3, (s_hw, t_hw, df, dm, mx)
+
+
+def test_from_pretrained_roundtrip_on_device(env, tmp_path):
+    """save_pretrained(local dir) -> from_pretrained(local dir): config.json + model.safetensors, no network."""
+    ufm_amd, R = env
+    _, prod = build_pair(env)
+    prod.save_pretrained(str(tmp_path / "ckpt"))
+    again = ufm_amd.UniFlowMatchConfidence.from_pretrained(str(tmp_path / "ckpt")).eval().to(DEV)
+    assert again.inference_resolution == prod.inference_resolution
+    src, tgt = u8((1, 56, 56, 3), 1).to(DEV), u8((1, 56, 56, 3), 2).to(DEV)
+    assert torch.equal(prod.predict_correspondences_batched(src, tgt).flow.flow_output, again.predict_correspondences_batched(src, tgt).flow.flow_output)
