@@ -75,7 +75,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvX3Args p) {
     const int tmi = bid / ntn, tni = bid - tmi * ntn;
     const int m0 = tmi * BM, n0 = tni * BN;
     const int cpt = p.Cin / BK;
-    const int nk = p.KH * p.KW * cpt;
+    const int ntaps = p.KH * p.KW;
+    const int nk = ntaps * cpt;
     const size_t ktot = (size_t)p.KH * p.KW * p.Cin;
 
     // ---- staging: wave w owns tile rows [32w, 32w+32) of A (2 pieces of 16 rows), both planes ----
@@ -103,8 +104,12 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvX3Args p) {
     const int w_lds_row0 = (BN >= 64 ? wave * W_ROWS_PER_WAVE : wave * 16);
 
     auto stage = [&](int buf, int kt) {
-        const int tap = kt / cpt, c0 = (kt - tap * cpt) * BK;
+        // channel-chunk outer, filter tap inner: the KH*KW taps of one 32-channel chunk are consecutive K-steps,
+        // so the +-1-pixel-shifted re-reads of the same input lines hit L1/L2 (tap-major order re-fetched the
+        // whole input 9x from beyond L2: 6.5 GB for the 296^2 layer, PMC FETCH_SIZE, profiles/r01)
+        const int chunk = kt / ntaps, tap = kt - chunk * ntaps, c0 = chunk * BK;
         const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        const size_t koff = (size_t)tap * p.Cin + c0;  // weight layout stays [Cout][KH][KW][Cin]
         char* sa = smem + buf * STAGE_BYTES + wave * 32 * 64;  // A hi plane, this wave's rows
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvX3Args p) {
             char* sb = smem + buf * STAGE_BYTES + 2 * A_PLANE + w_lds_row0 * 64;
 #pragma unroll
             for (int i = 0; i < W_PIECES; ++i) {
-                const uint16_t* src = gw[i] + (size_t)kt * BK;
+                const uint16_t* src = gw[i] + koff;
                 __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(sb + i * 1024), 16, 0, 0);
                 __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + p.w_plane), LDS_PTR(sb + W_PLANE + i * 1024), 16, 0, 0);
             }

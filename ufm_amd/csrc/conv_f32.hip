@@ -51,7 +51,8 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(ConvArgs p) {
     const int tmi = bid / ntn, tni = bid - tmi * ntn;
     const int m0 = tmi * BM, n0 = tni * BN;
     const int cpt = p.Cin / BK;  // K-steps per filter tap
-    const int nk = p.KH * p.KW * cpt;
+    const int ntaps = p.KH * p.KW;
+    const int nk = ntaps * cpt;
     const size_t ktot = (size_t)p.KH * p.KW * p.Cin;
 
     // ---- staging set-up: A pieces 4w..4w+3 (8 pixel rows each) ----
@@ -75,8 +76,12 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(ConvArgs p) {
         gw[i] = p.w + (size_t)(n0 + r) * ktot + (slot ^ ((r >> 1) & 7)) * 4;
     }
     auto stage = [&](int buf, int kt) {
-        const int tap = kt / cpt, c0 = (kt - tap * cpt) * BK;
+        // channel-chunk outer, filter tap inner: the KH*KW taps of one 32-channel chunk are consecutive K-steps,
+        // so the +-1-pixel-shifted re-reads of the same input lines hit L1/L2 (tap-major order re-fetched the
+        // whole input 9x from beyond L2: 6.5 GB for the 296^2 layer, PMC FETCH_SIZE, profiles/r01)
+        const int chunk = kt / ntaps, tap = kt - chunk * ntaps, c0 = chunk * BK;
         const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        const size_t koff = (size_t)tap * p.Cin + c0;  // weight layout stays [Cout][KH][KW][Cin]
         char* sa = smem + buf * STAGE_BYTES + wave * 4096;
         char* sb = smem + buf * STAGE_BYTES + A_BYTES + wave * (WPIECES * 1024);
 #pragma unroll
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(ConvArgs p) {
         }
 #pragma unroll
         for (int i = 0; i < WPIECES; ++i)
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gw[i] + (size_t)kt * BK), LDS_PTR(sb + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gw[i] + koff), LDS_PTR(sb + i * 1024), 16, 0, 0);
     };
 
     // ---- fragment offsets ----

@@ -133,9 +133,16 @@ template <int OUT_BF16>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ntn = p.N / BN;
+    const int ntn = p.N / BN, ntm = (p.M + BM - 1) / BM;
+    // XCD chunking + grouped rasterization: 64 consecutive logical tiles (what one XCD runs at a time) cover
+    // 8 M-panels x 8 N-panels, so each A and W panel is re-used 8x out of that XCD's L2 (N-fastest order
+    // streamed W from beyond L2 once per M-panel: 622 MB fetched for 51 MB of operands, PMC FETCH_SIZE)
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = bid / ntn, tn = bid - tm * ntn;
+    constexpr int GM = 8;
+    const int per_group = GM * ntn;
+    const int grp = bid / per_group, in_g = bid - grp * per_group;
+    const int gm = min(GM, ntm - grp * GM);
+    const int tm = grp * GM + in_g % gm, tn = in_g / gm;
     const int m0 = tm * BM, n0 = tn * BN;
     const int nk = p.K / BK;
 
