@@ -114,7 +114,7 @@ def test_gemm_rejects_bad_shapes(hip):
 
 
 # ----------------------------------------------------------------------------- LayerNorm
-@pytest.mark.parametrize("D", [128, 768, 1024])
+@pytest.mark.parametrize("D", [128, 192, 256, 768, 1024, 2048])
 @pytest.mark.parametrize("out_bf16", [False, True])
 def test_layernorm(hip, D, out_bf16):
     rows = 37

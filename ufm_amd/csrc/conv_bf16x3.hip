@@ -184,40 +184,51 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvX3Args p) {
             }
     }
 
-    // ---- epilogue: lane holds out[pixel fr][cb..cb+3] per (n, m) tile ----
+    // ---- epilogue, staged through LDS (the direct form touched 16 pixel rows x 8 B per wave instruction for each
+    // of: hi store, lo store, and up to four residual plane loads).  Each wave parks its (TM*16) x (TN*16) fp32 tile
+    // (bias added) in its own slice of the idle staging buffer, chunk index XOR row; afterwards a wave instruction
+    // covers whole pixel rows: TN*16 consecutive output channels = 128/64 B per plane, contiguous. ----
+    constexpr int ROWB = TN * 64;              // bytes per staged row (fp32)
+    constexpr int NCH = TN * 4;                // 16-byte chunks per row
+    constexpr int LPR = NCH;                   // lanes per row on the way out
+    constexpr int RPI = 64 / LPR;              // rows per wave instruction
+    __syncthreads();                           // all waves are done with the operand stages
+    char* ws = smem + wave * (TM * 16 * ROWB);
 #pragma unroll
-    for (int m = 0; m < TM; ++m) {
-        const int pix = m0 + wm * (TM * 16) + m * 16 + fr;
+    for (int n = 0; n < TN; ++n) {
+        const int cb = n0 + wn * (TN * 16) + n * 16 + fq * 4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = *(const f32x4*)(p.bias + (p.shuffle ? cb % p.Co : cb));
+#pragma unroll
+        for (int m = 0; m < TM; ++m) {
+            const int r = m * 16 + fr;
+            *(f32x4*)(ws + r * ROWB + (((n * 4 + fq) ^ (r & (NCH - 1))) << 4)) = acc[n][m] + bv;
+        }
+    }
+    const int orr = lane / LPR, oc = lane % LPR;
+#pragma unroll
+    for (int pass = 0; pass < TM * 16 / RPI; ++pass) {
+        const int r = pass * RPI + orr;
+        f32x4 v = *(const f32x4*)(ws + r * ROWB + ((oc ^ (r & (NCH - 1))) << 4));
+        const int pix = m0 + wm * (TM * 16) + r;
         if (pix >= p.M) continue;
-        int sb = 0, sy = 0, sx = 0;
+        const int cb = n0 + wn * (TN * 16) + oc * 4;
         if (p.shuffle) {
-            sx = pix % p.Wo;
-            const int t = pix / p.Wo;
-            sy = t % p.Ho;
-            sb = t / p.Ho;
-        }
-#pragma unroll
-        for (int n = 0; n < TN; ++n) {
-            const int cb = n0 + wn * (TN * 16) + n * 16 + fq * 4;
-            f32x4 v = acc[n][m];
-            if (p.shuffle) {
-                const int tapo = cb / p.Co, co = cb - tapo * p.Co;
-                const int kh = tapo / p.shuffle, kw = tapo - kh * p.shuffle;
-                if (p.bias) v += *(const f32x4*)(p.bias + co);
-                const size_t o = (((size_t)sb * (p.Ho * p.shuffle) + sy * p.shuffle + kh) * (p.Wo * p.shuffle) + sx * p.shuffle + kw) * p.Co + co;
-                split_store4(p.out + o, p.out_plane, v);
-                continue;
-            }
-            if (p.bias) v += *(const f32x4*)(p.bias + cb);
-            if (p.act != UFM_ACT_NONE) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act);
-            }
-            const size_t o = (size_t)pix * p.Cout + cb;
-            if (p.res1) v += split_load4(p.res1 + o, p.out_plane);
-            if (p.res2) v += split_load4(p.res2 + o, p.out_plane);
+            const int sx = pix % p.Wo, t = pix / p.Wo, sy = t % p.Ho, sb = t / p.Ho;
+            const int tapo = cb / p.Co, co = cb - tapo * p.Co;
+            const int kh = tapo / p.shuffle, kw = tapo - kh * p.shuffle;
+            const size_t o = (((size_t)sb * (p.Ho * p.shuffle) + sy * p.shuffle + kh) * (p.Wo * p.shuffle) + sx * p.shuffle + kw) * p.Co + co;
             split_store4(p.out + o, p.out_plane, v);
+            continue;
         }
+        if (p.act != UFM_ACT_NONE) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act);
+        }
+        const size_t o = (size_t)pix * p.Cout + cb;
+        if (p.res1) v += split_load4(p.res1 + o, p.out_plane);
+        if (p.res2) v += split_load4(p.res2 + o, p.out_plane);
+        split_store4(p.out + o, p.out_plane, v);
     }
 }
 
