@@ -146,8 +146,11 @@ def test_attention_bf16(hip, B, N, H):
 
 
 @pytest.mark.parametrize("B,N,H", [(1, 17, 1), (2, 100, 2), (2, 1370, 2), (1, 2738, 3), (1, 64, 1), (1, 129, 1)])
-def test_attention_bf16_prescaled_log2_kernel(hip, B, N, H):
-    """scale == 0 path: Q columns pre-multiplied by scale*log2(e) (what the QKV GEMM epilogue does), deferred rescale."""
+@pytest.mark.parametrize("variant", [0, 3])
+def test_attention_bf16_prescaled_log2_kernel(hip, B, N, H, variant):
+    """scale == 0 path: Q columns pre-multiplied by scale*log2(e) (what the QKV GEMM epilogue does), deferred rescale.
+    variant 0 = v2 (default), 3 = cross-tile pipelined v3 (opt-in)."""
+    hip.lib().ufm_debug_set_attn_variant(variant)
     qkv = rnd(B * N, 3 * H * 64, seed=N, scale=1.5)
     qkv_b = bf16r(qkv)
     ref = attn_ref(qkv_b, B, N, H, 0.125)
@@ -156,13 +159,17 @@ def test_attention_bf16_prescaled_log2_kernel(hip, B, N, H):
     pre = bf16r(pre.reshape(B * N, -1))
     pre.reshape(B * N, 3, H * 64)[:, 1:] = qkv_b.reshape(B * N, 3, H * 64)[:, 1:]
     out = torch.zeros(B * N, H * 64, device=DEV, dtype=torch.bfloat16)
-    hip.attention(pre.to(DEV).bfloat16(), out, B, N, H, 0.0)
+    try:
+        hip.attention(pre.to(DEV).bfloat16(), out, B, N, H, 0.0)
+    finally:
+        hip.lib().ufm_debug_set_attn_variant(0)
     err = (out.float().cpu().double() - ref).abs().max().item()
     assert err <= 3e-2, err  # + one extra bf16 rounding of the already-rounded test Q (not present in the fused pipeline)
 
 
+@pytest.mark.parametrize("variant", [0, 3])
 @pytest.mark.parametrize("growth", [3.0, 30.0])
-def test_attention_bf16_prescaled_deferred_rescale_branches(hip, growth):
+def test_attention_bf16_prescaled_deferred_rescale_branches(hip, growth, variant):
     """Late keys whose scores exceed the running reference by less / more than the deferral threshold (rule 26):
     both the 'keep the reference' and the 'move the reference' paths must give the same softmax."""
     B, N, H = 1, 300, 1
@@ -175,7 +182,11 @@ def test_attention_bf16_prescaled_deferred_rescale_branches(hip, growth):
     pre[:, :64] = bf16r(pre[:, :64] * c)
     refp = attn_ref(torch.cat([pre[:, :64] / c, pre[:, 64:]], 1), B, N, H, 0.125)  # exact statement of the pre-rounded problem
     out = torch.zeros(N, 64, device=DEV, dtype=torch.bfloat16)
-    hip.attention(pre.to(DEV).bfloat16(), out, B, N, H, 0.0)
+    hip.lib().ufm_debug_set_attn_variant(variant)
+    try:
+        hip.attention(pre.to(DEV).bfloat16(), out, B, N, H, 0.0)
+    finally:
+        hip.lib().ufm_debug_set_attn_variant(0)
     assert (out.float().cpu().double() - refp).abs().max().item() <= 2e-2
     assert (out.float().cpu().double() - ref).abs().max().item() <= 6e-2
 

@@ -689,10 +689,11 @@ extern "C" int ufm_attention_bf16(const uint16_t* qkv, uint16_t* out, int B, int
     UFM_REQUIRE(B > 0 && N > 0 && H > 0 && (int64_t)((N + QB - 1) / QB) * H * B < (1ll << 31), "ufm_attention_bf16: bad shape B=%d N=%d H=%d", B, N, H);
     UFM_REQUIRE(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 8) == 0, "ufm_attention_bf16: misaligned pointer");
     dim3 grid(((N + QB - 1) / QB) * H * B), block(256);
-    if (scale == 0.0f && g_attn_debug != 2)  // Q pre-scaled by softmax_scale*log2(e): scores already in log2 units
+    if (scale == 0.0f && g_attn_debug == 3)  // opt-in: cross-tile pipelined v3 (+3..10 % on randn data in tools/kbench.py,
+                                             // but 26 % SLOWER inside the real pipeline: 8.9 vs 6.6 ms per step)
         hipLaunchKernelGGL(attn_bf16_kernel_v3, grid, block, 0, (hipStream_t)stream, qkv, out, N, H);
-    else if (scale == 0.0f)  // A/B hook: the unpipelined v2
-        hipLaunchKernelGGL(attn_bf16_kernel_v2, grid, block, 0, (hipStream_t)stream, qkv, out, N, H, 0);
+    else if (scale == 0.0f)  // Q pre-scaled by softmax_scale*log2(e): scores already in log2 units
+        hipLaunchKernelGGL(attn_bf16_kernel_v2, grid, block, 0, (hipStream_t)stream, qkv, out, N, H, g_attn_debug);
     else
         hipLaunchKernelGGL(attn_bf16_kernel, grid, block, 0, (hipStream_t)stream, qkv, out, N, H, scale * 1.44269504088896340736f);
     UFM_CHECK_LAUNCH("ufm_attention_bf16");

@@ -120,6 +120,55 @@ __global__ __launch_bounds__(256) void upsample_kernel(const void* __restrict__ 
     }
 }
 
+
+// split-format upsample, 8 channels (16 B per plane) per thread: half the memory instructions of the 4-channel form
+__device__ __forceinline__ void ld_split8(const uint16_t* hi_ptr, size_t plane, float (&v)[8]) {
+    const u32x4 ph = *(const u32x4*)hi_ptr;
+    const u32x4 pl = *(const u32x4*)(hi_ptr + plane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[2 * j] = __uint_as_float(ph[j] << 16) + __uint_as_float(pl[j] << 16);
+        v[2 * j + 1] = __uint_as_float(ph[j] & 0xffff0000u) + __uint_as_float(pl[j] & 0xffff0000u);
+    }
+}
+__global__ __launch_bounds__(256) void upsample_split8_kernel(const uint16_t* __restrict__ in, int B, int H, int W, int C,
+                                                              uint16_t* __restrict__ out, int Ho, int Wo, float sy, float sx) {
+    const size_t in_plane = (size_t)B * H * W * C, out_plane = (size_t)B * Ho * Wo * C;
+    const int cq = C >> 3;
+    const size_t total = (size_t)B * Ho * Wo * cq;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(t % cq);
+        const size_t pix = t / cq;
+        const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((size_t)Wo * Ho));
+        const float fy = sy * oy, fx = sx * ox;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+        const float ly1 = fy - y0, lx1 = fx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        const size_t boff = (size_t)b * H * W * C + c8 * 8;
+        float v00[8], v01[8], v10[8], v11[8];
+        ld_split8(in + boff + ((size_t)y0 * W + x0) * C, in_plane, v00);
+        ld_split8(in + boff + ((size_t)y0 * W + x1) * C, in_plane, v01);
+        ld_split8(in + boff + ((size_t)y1 * W + x0) * C, in_plane, v10);
+        ld_split8(in + boff + ((size_t)y1 * W + x1) * C, in_plane, v11);
+        unsigned ph[4], pl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float r[2], h[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int k = 2 * j + e;
+                r[e] = ly0 * (lx0 * v00[k] + lx1 * v01[k]) + ly1 * (lx0 * v10[k] + lx1 * v11[k]);
+                h[e] = bf16_to_f32(f32_to_bf16(r[e]));
+            }
+            ph[j] = pack_bf16x2(h[0], h[1]);
+            pl[j] = pack_bf16x2(r[0] - h[0], r[1] - h[1]);
+        }
+        uint16_t* o = out + pix * C + c8 * 8;
+        *(u32x4*)o = u32x4{ph[0], ph[1], ph[2], ph[3]};
+        *(u32x4*)(o + out_plane) = u32x4{pl[0], pl[1], pl[2], pl[3]};
+    }
+}
+
 struct TailArgs {
     int kind[4];
     float a[4];
@@ -337,7 +386,9 @@ extern "C" int ufm_upsample_bilinear_nhwc(const void* in, int dtype, int B, int 
     const float sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
     const int Hs = crop_h > 0 ? crop_h : Ho, Ws = crop_w > 0 ? crop_w : Wo;
     const size_t total = (size_t)B * Hs * Ws * (C / 4);
-    if (dtype == UFM_BF16X2)
+    if (dtype == UFM_BF16X2 && C % 8 == 0)
+        hipLaunchKernelGGL(upsample_split8_kernel, stream_grid((size_t)B * Hs * Ws * (C / 8)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)in, B, H, W, C, (uint16_t*)out, Hs, Ws, sy, sx);
+    else if (dtype == UFM_BF16X2)
         hipLaunchKernelGGL(upsample_kernel<1>, stream_grid(total), dim3(256), 0, (hipStream_t)stream, in, B, H, W, C, out, Hs, Ws, sy, sx);
     else
         hipLaunchKernelGGL(upsample_kernel<0>, stream_grid(total), dim3(256), 0, (hipStream_t)stream, in, B, H, W, C, out, Hs, Ws, sy, sx);
