@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--numerics", default="fast", choices=["fast", "parity"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--serial-heads", action="store_true", help="run the two DPT heads on one stream")
     ap.add_argument("--micro-batches", type=int, default=2, help="concurrent micro-batches (HIP streams) per GPU; 1 = single stream")
     args = ap.parse_args()
 
@@ -90,6 +91,7 @@ def main():
     init_weights_(model, seed=0)  # deterministic CPU RNG: identical weights on every rank
     model = model.to(dev).set_numerics(args.numerics)
     model.engine().micro_batches = args.micro_batches
+    model.engine().concurrent_heads = not args.serial_heads
 
     B = args.batch
     g = torch.Generator().manual_seed(1234 + rank)  # each rank owns its own slice of the global batch

@@ -409,6 +409,8 @@ def unsplit(s):
         (2, 37, 37, 96, 64, 3, 2, 1, False, 0, 0),
         (1, 20, 13, 128, 96, 1, 1, 0, False, 2, 1),
         (1, 30, 30, 256, 256, 3, 1, 1, True, 0, 1),
+        (4, 128, 128, 32, 128, 3, 1, 1, True, 0, 1),   # >= 400 blocks: the 128x128 tile path
+        (4, 128, 128, 32, 64, 3, 1, 1, False, 2, 0),   # 128x64 tile path
     ],
 )
 def test_conv2d_bf16x3(hip, B, H, W, Cin, Cout, k, stride, pad, relu_in, act, nres):

@@ -18,7 +18,7 @@
 
 namespace {
 
-constexpr int BM = 128, BK = 32;
+constexpr int BK = 32;
 
 struct ConvX3Args {
     const uint16_t* in;   // [2][B*H*W][Cin]
@@ -59,9 +59,12 @@ __device__ __forceinline__ f32x4 split_load4(const uint16_t* hi_ptr, long long p
     return v;
 }
 
-template <int BN>
+// BM x BN tile: 128x{128,64,32} for the big maps; 64x64 for the small grids (19^2 / 37^2: with 128-row tiles only 46-172
+// blocks exist, each a 72-216 step latency-bound K-loop -- 4x more, smaller blocks co-reside and overlap their DMA waits)
+template <int BM, int BN>
 __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvX3Args p) {
     constexpr int WN = BN >= 64 ? 2 : 1, WM = 4 / WN;
+    constexpr int A_RPW = BM / 4, A_PIECES = A_RPW / 16;  // A rows / DMA pieces per wave and plane
     constexpr int TM = (BM / WM) / 16, TN = (BN / WN) / 16;
     constexpr int A_PLANE = BM * BK * 2, W_PLANE = BN * BK * 2;         // bytes per plane per stage
     constexpr int STAGE_BYTES = 2 * (A_PLANE + W_PLANE);
@@ -79,13 +82,13 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvX3Args p) {
     const int nk = ntaps * cpt;
     const size_t ktot = (size_t)p.KH * p.KW * p.Cin;
 
-    // ---- staging: wave w owns tile rows [32w, 32w+32) of A (2 pieces of 16 rows), both planes ----
+    // ---- staging: wave w owns tile rows [A_RPW*w, A_RPW*(w+1)) of A (pieces of 16 rows), both planes ----
     const int srow = lane >> 2, slot = lane & 3;
-    int a_iy0[2], a_ix0[2], a_chunk[2];
-    size_t a_img[2];
+    int a_iy0[A_PIECES], a_ix0[A_PIECES], a_chunk[A_PIECES];
+    size_t a_img[A_PIECES];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = wave * 32 + i * 16 + srow;
+    for (int i = 0; i < A_PIECES; ++i) {
+        const int r = wave * A_RPW + i * 16 + srow;
         a_chunk[i] = (slot ^ swz(r)) * 8;
         const int m = min(m0 + r, p.M - 1);
         const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
@@ -110,9 +113,9 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvX3Args p) {
         const int chunk = kt / ntaps, tap = kt - chunk * ntaps, c0 = chunk * BK;
         const int kh = tap / p.KW, kw = tap - kh * p.KW;
         const size_t koff = (size_t)tap * p.Cin + c0;  // weight layout stays [Cout][KH][KW][Cin]
-        char* sa = smem + buf * STAGE_BYTES + wave * 32 * 64;  // A hi plane, this wave's rows
+        char* sa = smem + buf * STAGE_BYTES + wave * A_RPW * 64;  // A hi plane, this wave's rows
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < A_PIECES; ++i) {
             const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
             const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             const uint16_t* src = ok ? p.in + (a_img[i] + (size_t)iy * p.W + ix) * p.Cin + c0 + a_chunk[i] : p.zero + a_chunk[i];
@@ -259,13 +262,16 @@ extern "C" int ufm_conv2d_nhwc_bf16x3(const uint16_t* in, int B, int H, int W, i
     ConvX3Args p{in, weight, bias, res1, res2, zero_page, out,
                  (long long)B * H * W * Cin, (long long)Cout * KH * KW * Cin, Mout * Co,
                  B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, (int)M, relu_in, act, shuffle, Co};
-    const int ntm = (int)((M + BM - 1) / BM);
-    if (Cout % 128 == 0) {
-        hipLaunchKernelGGL(conv_x3_kernel<128>, dim3(ntm * (Cout / 128)), dim3(256), 0, (hipStream_t)stream, p);
+    const int ntm = (int)((M + 127) / 128);
+    const long long blocks128 = (long long)ntm * (Cout % 128 == 0 ? Cout / 128 : Cout % 64 == 0 ? Cout / 64 : Cout / 32);
+    if (Cout % 64 == 0 && blocks128 < 400) {  // small grid: 64x64 tiles, several co-resident blocks per CU
+        hipLaunchKernelGGL((conv_x3_kernel<64, 64>), dim3((unsigned)(((M + 63) / 64) * (Cout / 64))), dim3(256), 0, (hipStream_t)stream, p);
+    } else if (Cout % 128 == 0) {
+        hipLaunchKernelGGL((conv_x3_kernel<128, 128>), dim3(ntm * (Cout / 128)), dim3(256), 0, (hipStream_t)stream, p);
     } else if (Cout % 64 == 0) {
-        hipLaunchKernelGGL(conv_x3_kernel<64>, dim3(ntm * (Cout / 64)), dim3(256), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((conv_x3_kernel<128, 64>), dim3(ntm * (Cout / 64)), dim3(256), 0, (hipStream_t)stream, p);
     } else {
-        hipLaunchKernelGGL(conv_x3_kernel<32>, dim3(ntm * (Cout / 32)), dim3(256), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((conv_x3_kernel<128, 32>), dim3(ntm * (Cout / 32)), dim3(256), 0, (hipStream_t)stream, p);
     }
     UFM_CHECK_LAUNCH("ufm_conv2d_nhwc_bf16x3");
     return UFM_OK;

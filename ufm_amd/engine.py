@@ -140,6 +140,8 @@ class Engine:
         self._tls = threading.local()  # .ns = workspace namespace of the micro-batch this thread is running
         self.micro_batches = 2  # >1: the batch is split into micro-batches that run concurrently on separate HIP streams
         self._streams: List[torch.cuda.Stream] = []
+        self.concurrent_heads = False  # measured: no gain on top of the two concurrent micro-batches (166 vs 168 pairs/s)
+        self._head_streams: Dict[str, List[torch.cuda.Stream]] = {}
 
     # ------------------------------------------------------------------ packing
     def _pack(self) -> None:
@@ -521,8 +523,28 @@ class Engine:
         dims = [D, Di, Di, Di]
 
         out: Dict[str, Any] = {}
-        for tag, hw in self.heads.items():
-            out[tag] = self._head(hw, tag, levels, dims, B, gh, gw, H, W)
+        if len(self.heads) > 1 and self.concurrent_heads and hip.TIMER is None:
+            # the heads only share their (read-only) input pyramid: run them on separate HIP streams so the
+            # latency-bound small-grid layers of one overlap the large layers of the other
+            main = torch.cuda.current_stream(self.dev)
+            side_streams = self._head_streams.setdefault(getattr(self._tls, "ns", ""), [])
+            while len(side_streams) < len(self.heads) - 1:
+                side_streams.append(torch.cuda.Stream(device=self.dev))
+            tags = list(self.heads.items())
+            for (tag, hw), st in zip(tags[1:], side_streams):
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    out[tag] = self._head(hw, tag, levels, dims, B, gh, gw, H, W)
+            out[tags[0][0]] = self._head(tags[0][1], tags[0][0], levels, dims, B, gh, gw, H, W)
+            for (tag, _), st in zip(tags[1:], side_streams):
+                main.wait_stream(st)
+                for v in out[tag].values():
+                    for t in v.values():
+                        if isinstance(t, torch.Tensor):
+                            t.record_stream(main)
+        else:
+            for tag, hw in self.heads.items():
+                out[tag] = self._head(hw, tag, levels, dims, B, gh, gw, H, W)
 
         if self.refine:  # ufm.py:949-1007
             lvl3a = self.buf("lvl3_v1_f32", (B * Np, Di))
