@@ -178,9 +178,21 @@ def main():
         mf = {k: v for k, v in kernels.items() if v.get("bound") == "mfma"}
         dom = max(mf, key=lambda k: mf[k]["ms_per_step"])
         d = mf[dom]
+        # HBM traffic per launch: PMC counters cannot be read from inside the process; they come from the committed
+        # summary of `tools/pmc_traffic.sh` (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc passes over
+        # this same command), averaged over the launches of the family like `achieved`.
+        pmc = {}
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_step_summary.json")
+        if os.path.exists(pmc_path) and B == 8 and res == 518 and args.numerics == "fast":
+            pmc = json.load(open(pmc_path))
+        for k, v in kernels.items():
+            if k in pmc and "hbm_bytes_per_launch" in pmc[k]:
+                v["traffic"] = pmc[k]["hbm_bytes_per_launch"]
+                v["mfma_busy_frac_pmc"] = pmc[k].get("mfma_busy_frac")
         line["roofline"] = {
             "kernel": dom, "bound": "mfma", "achieved": d["achieved"], "peak": d["peak"], "unit": "TFLOP/s", "frac": d["frac"],
-            "traffic": None, "avg_launch_us": d["avg_launch_us"], "algorithmic_gflop_per_launch": d["algorithmic_gflop"] / d["launches"],
+            "traffic": d.get("traffic"), "traffic_unit": "HBM bytes per launch (PMC, profiles/r01/pmc_step_summary.json)",
+            "avg_launch_us": d["avg_launch_us"], "algorithmic_gflop_per_launch": d["algorithmic_gflop"] / d["launches"],
         }
         if "ufm_attention_bf16" in kernels:
             a = kernels["ufm_attention_bf16"]

@@ -78,7 +78,7 @@ def test_gemm_bf16(hip, M, N, K, act, use_gamma, use_res, out_bf16, row_mod, row
     assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 28])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 28])
 @pytest.mark.parametrize("M,N,K,out_bf16", [(256 * 70 + 13, 768, 192, True), (256 * 64 + 200, 1024, 640, False)])
 def test_gemm_large_tile_variants(hip, variant, M, N, K, out_bf16):
     """All three tile shapes (128x128 / 256x128 3-stage / 256x256 4-stage ring) against the same fp64 statement,

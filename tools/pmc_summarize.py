@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Summarise tools/pmc_traffic.sh output into profiles/<round>/pmc_step_summary.json: per kernel family, average
+per-launch HBM bytes (FETCH_SIZE is in KiB and is doubled: on gfx950 it reports exactly half the bytes of wide
+coalesced reads -- MI355X_MICROARCH.md section HBM; WRITE_SIZE is exact for 16-B stores), MFMA-busy fraction, LDS
+bank-conflict cycles."""
+import collections, csv, glob, json, sys
+out_path = sys.argv[1] if len(sys.argv) > 1 else "profiles/r01/pmc_step_summary.json"
+FAM = {"gemm_bf16_kernel": "ufm_gemm_bf16", "attn_bf16_kernel": "ufm_attention_bf16", "conv_x3_kernel": "ufm_conv2d_nhwc_bf16x3",
+       "layernorm_kernel": "ufm_layernorm", "upsample": "ufm_upsample_bilinear_nhwc", "head_tail": "ufm_head_tail",
+       "patchify": "ufm_patchify", "unmap": "ufm_unmap", "conv_f32": "ufm_conv2d_nhwc_f32"}
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in ("pmc_step_fetch", "pmc_step_write", "pmc_step_util"):
+    for f in glob.glob(f"gpurun_out/{d}/*/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            fam = next((v for k, v in FAM.items() if k in r["Kernel_Name"]), None)
+            if fam:
+                acc[fam][r["Counter_Name"]].append(float(r["Counter_Value"]))
+res = {}
+for fam, d in acc.items():
+    a = {k: sum(v) / len(v) for k, v in d.items()}
+    e = {"launches_sampled": len(next(iter(d.values())))}
+    if "FETCH_SIZE" in a:
+        e["hbm_read_bytes_per_launch"] = a["FETCH_SIZE"] * 1024 * 2
+    if "WRITE_SIZE" in a:
+        e["hbm_write_bytes_per_launch"] = a["WRITE_SIZE"] * 1024
+    if "FETCH_SIZE" in a and "WRITE_SIZE" in a:
+        e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in a and a.get("GRBM_GUI_ACTIVE"):
+        e["mfma_busy_frac"] = a["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * a["GRBM_GUI_ACTIVE"] / 8)
+        e["wave_wait_frac"] = a["SQ_WAIT_ANY"] / a["SQ_WAVE_CYCLES"]
+        e["lds_bank_conflict_cycles"] = a["SQ_LDS_BANK_CONFLICT"]
+    res[fam] = e
+json.dump(res, open(out_path, "w"), indent=1)
+for k, v in res.items():
+    print(k, {a: (round(b, 3) if isinstance(b, float) and b < 10 else int(b)) for a, b in v.items()})

@@ -1,0 +1,133 @@
+// Shared pieces of the bf16 GEMM kernels (gemm_bf16.hip, gemm_bf16_8ph.hip): argument block, fused epilogues.
+#pragma once
+#include "common.h"
+
+struct GemmArgs {
+    const uint16_t* A;
+    const uint16_t* W;
+    const float* bias;
+    const float* gamma;
+    const float* res;
+    void* out;
+    int lda, ldw, M, N, K;
+    int act, ldres, res_row_mod, ldo, out_row_group;
+    int debug;  // diagnostics only (tools/): 1 = every block reads tile (0,0), 2 = no DMA
+};
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int STAGE_BYTES = (BM + BN) * BK * 2;  // 32 KiB
+
+
+// lane holds out[row][nb..nb+3] for each (n_rep, m_rep) tile of its wave's 64x64 block
+template <int OUT_BF16>
+__device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[4][4], int row0, int col0, int fr, int fq) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int row = row0 + m * 16 + fr;
+        if (row >= p.M) continue;
+        const int rrow = (p.res_row_mod > 0) ? (row % p.res_row_mod) : row;
+        const int orow = (p.out_row_group > 0)
+                             ? (row / p.out_row_group) * (p.out_row_group + 1) + 1 + row % p.out_row_group
+                             : row;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int nb = col0 + n * 16 + fq * 4;
+            f32x4 v = acc[n][m];
+            if (p.bias) {
+                const f32x4 bv = *(const f32x4*)(p.bias + nb);
+                v += bv;
+            }
+            if (p.act == UFM_ACT_GELU && OUT_BF16) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = gelu_erf_fast(v[j]);
+            } else if (p.act != UFM_ACT_NONE) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act);
+            }
+            if (p.gamma) {
+                const f32x4 gv = *(const f32x4*)(p.gamma + nb);
+                v *= gv;
+            }
+            if (p.res) {
+                const f32x4 rv = *(const f32x4*)(p.res + (size_t)rrow * p.ldres + nb);
+                v += rv;
+            }
+            if (OUT_BF16) {
+                u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                *(u32x2*)((uint16_t*)p.out + (size_t)orow * p.ldo + nb) = pk;
+            } else {
+                *(f32x4*)((float*)p.out + (size_t)orow * p.ldo + nb) = v;
+            }
+        }
+    }
+}
+
+
+// LDS-staged epilogue for the 128x128 kernel.  Ablation (tools/ksweep.py) showed the direct epilogue --
+// a wave store touching 16 rows x 32 B -- costs ~50 us of a 190 us QKV GEMM.  Each wave parks its 64x64
+// fp32 tile in its own 16 KiB of the (now idle) staging buffer, 16-byte chunk index XOR (row & 15)
+// (conflict-free for both the accumulator-shaped writes and the row-shaped reads), then every wave
+// instruction moves 4 whole rows: 256-B fp32 / 128-B bf16 contiguous per row, for the residual read
+// (in-place update) and the store alike.  Within a wave LDS ops are in order: no barrier after the writes.
+template <int OUT_BF16>
+__device__ __forceinline__ void epilogue_lds(const GemmArgs& p, f32x4 (&acc)[4][4], char* wave_lds, int row0, int col0,
+                                             int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int nb = col0 + n * 16 + fq * 4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f}, gv = {1.f, 1.f, 1.f, 1.f};
+        if (p.bias) bv = *(const f32x4*)(p.bias + nb);
+        if (p.gamma) gv = *(const f32x4*)(p.gamma + nb);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            f32x4 v = acc[n][m] + bv;
+            if (p.act == UFM_ACT_GELU && OUT_BF16) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = gelu_erf_fast(v[j]);
+            } else if (p.act != UFM_ACT_NONE) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act);
+            }
+            if (p.gamma) v *= gv;
+            const int r = m * 16 + fr;
+            *(f32x4*)(wave_lds + r * 256 + (((n * 4 + fq) ^ (r & 15)) << 4)) = v;
+        }
+    }
+    const int rr = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int pass = 0; pass < 16; ++pass) {
+        const int r = pass * 4 + rr;
+        f32x4 v = *(const f32x4*)(wave_lds + r * 256 + ((c ^ (r & 15)) << 4));
+        const int row = row0 + r;
+        if (row >= p.M) continue;
+        const int nb = col0 + c * 4;
+        if (p.res) {
+            const int rrow = (p.res_row_mod > 0) ? (row % p.res_row_mod) : row;
+            v += *(const f32x4*)(p.res + (size_t)rrow * p.ldres + nb);
+        }
+        const int orow = (p.out_row_group > 0)
+                             ? (row / p.out_row_group) * (p.out_row_group + 1) + 1 + row % p.out_row_group
+                             : row;
+        if (OUT_BF16) {
+            u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            *(u32x2*)((uint16_t*)p.out + (size_t)orow * p.ldo + nb) = pk;
+        } else {
+            *(f32x4*)((float*)p.out + (size_t)orow * p.ldo + nb) = v;
+        }
+    }
+}
+
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+}  // namespace
+
+// gemm_bf16_8ph.hip: 256x256 8-phase kernel (N % 256 == 0, K >= 128, 32-bit operand offsets)
+int ufm_launch_gemm_8ph(const GemmArgs& p, int out_dtype, hipStream_t stream);
