@@ -97,6 +97,8 @@ int ufm_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M,
 int ufm_debug_set_gemm_variant(int force_small);
 /* Tuning hook (timing diagnostics only; 0 = normal). */
 int ufm_debug_set_attn_variant(int v);
+/* Tuning hook for ufm_conv2d_nhwc_bf16x3: 0 = auto, 1 = 128-row kernels only, 2 = 256x256 8-phase kernel wherever applicable. */
+int ufm_debug_set_conv_variant(int v);
 
 /* =====================================================================================
  * LayerNorm over the channel dim, eps inside the sqrt ([U] Block.norm1/norm2, encoder .norm,
@@ -160,11 +162,15 @@ int ufm_conv2d_nhwc_f32(const float* in, int B, int H, int W, int Cin, const flo
  * weight / res / out are in the UFM_BF16X2 split format and every product is evaluated as
  * hi*hi + hi*lo + lo*hi (3 bf16 MFMAs, fp32 accumulate; ~2^-17 relative error per dot product --
  * tighter than the TF32 cuDNN applies to the reference's fp32 island on NVIDIA by default).
- * weight: [2][Cout][KH][KW][Cin] pre-split at pack time.  Same fused epilogue minus gamma. */
+ * weight: [2][Cout][KH][KW][Cin] pre-split at pack time.  Same fused epilogue minus gamma.
+ * out_relu (optional, may be NULL): a second output relu(out) in the same layout -- [U] ResidualConvUnit
+ * is conv2(relu(conv1(relu(x)))) + x, so the producer of x writes x (for the skip) AND relu(x) (conv1's
+ * input), which takes the ReLU out of the consumer's MFMA loop (bit-identical to relu_in=1). */
 int ufm_conv2d_nhwc_bf16x3(const uint16_t* in, int B, int H, int W, int Cin, const uint16_t* weight,
                            int Cout, int KH, int KW, int stride, int pad, int relu_in,
                            const float* bias, int act, const uint16_t* res1, const uint16_t* res2,
-                           int shuffle, uint16_t* out, const uint16_t* zero_page, void* stream);
+                           int shuffle, uint16_t* out, uint16_t* out_relu, const uint16_t* zero_page,
+                           void* stream);
 
 /* Bilinear resize, align_corners=True, NHWC fp32 ([U] FeatureFusionBlock x2 upsample,
  * DPTRegressionProcessor interpolate-to-target).  src = dst*(in-1)/(out-1).  crop_h/crop_w > 0:

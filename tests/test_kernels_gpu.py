@@ -78,7 +78,7 @@ def test_gemm_bf16(hip, M, N, K, act, use_gamma, use_res, out_bf16, row_mod, row
     assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 28])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 28])
 @pytest.mark.parametrize("M,N,K,out_bf16", [(256 * 70 + 13, 768, 192, True), (256 * 64 + 200, 1024, 640, False)])
 def test_gemm_large_tile_variants(hip, variant, M, N, K, out_bf16):
     """All three tile shapes (128x128 / 256x128 3-stage / 256x256 4-stage ring) against the same fp64 statement,
@@ -433,6 +433,47 @@ def test_conv2d_bf16x3(hip, B, H, W, Cin, Cout, k, stride, pad, relu_in, act, nr
     err = (got - ref).abs().max().item()
     # split inputs carry 2^-17 relative error, the dropped lo*lo term 2^-16 per product, the split store 2^-17
     assert err <= 4e-5 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize(
+    "B,H,W,Cin,Cout,k,stride,pad,relu_in,act,nres,shuffle",
+    [
+        (2, 37, 37, 64, 256, 3, 1, 1, True, 0, 2, 0),     # ragged M (2738 px), both residuals, ReLU on the input
+        (1, 75, 61, 96, 256, 3, 2, 1, False, 2, 0, 0),    # stride 2, ReLU on the output
+        (3, 23, 17, 32, 512, 1, 1, 0, False, 0, 1, 0),    # 1x1, Cin = 32: a single K-tile, below the 8-phase kernel's minimum -> falls back
+        (3, 23, 17, 64, 512, 1, 1, 0, False, 0, 1, 0),    # 1x1, nt = 2 (prologue only + tail waits)
+        (2, 9, 11, 96, 1024, 1, 1, 0, False, 0, 0, 2),    # ConvTranspose (pixel-shuffle store), Co = 256
+        (8, 148, 148, 32, 256, 3, 1, 1, True, 0, 1, 0),   # 685 tiles: auto = 2 whole rounds on the 8-phase kernel + 128-row rest
+    ],
+)
+def test_conv2d_bf16x3_8phase_bit_identical(hip, B, H, W, Cin, Cout, k, stride, pad, relu_in, act, nres, shuffle):
+    """The 256x256 8-phase kernel does the same arithmetic in the same order as the 128-row kernels: outputs must be
+    BIT-identical (forced variant 2 = 8-phase everywhere, and variant 0 = the auto/hybrid split, vs variant 1)."""
+    lib = hip.lib()
+    x = split(nhwc(rnd(B, Cin, H, W, seed=1))).to(DEV)
+    w = split(rnd(Cout, k, k, Cin, seed=2, scale=(Cin * k * k) ** -0.5)).to(DEV)
+    b = rnd(Cout // (shuffle * shuffle) if shuffle else Cout, seed=3, scale=0.1).to(DEV)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    oshape = (2, B, Ho * shuffle, Wo * shuffle, Cout // (shuffle * shuffle)) if shuffle else (2, B, Ho, Wo, Cout)
+    res = [split(rnd(B, Ho, Wo, Cout, seed=10 + i)).to(DEV) for i in range(nres)] + [None, None]
+    zero = torch.zeros(256, device=DEV)
+    outs = {}
+    try:
+        for variant in (1, 2, 0):
+            lib.ufm_debug_set_conv_variant(variant)
+            out = torch.full(oshape, 7.0, device=DEV, dtype=torch.bfloat16)
+            orl = None if shuffle else torch.full(oshape, 7.0, device=DEV, dtype=torch.bfloat16)
+            hip.conv2d_x3(x, B, H, W, Cin, w, Cout, k, k, stride, pad, out, zero, relu_in=relu_in, bias=b, act=act,
+                          res1=res[0], res2=res[1], shuffle=shuffle, out_relu=orl)
+            outs[variant] = (out.cpu(), None if shuffle else orl.cpu())
+    finally:
+        lib.ufm_debug_set_conv_variant(0)
+    for v in (2, 0):
+        assert torch.equal(outs[1][0].view(torch.int16), outs[v][0].view(torch.int16))
+        if not shuffle:
+            assert torch.equal(outs[1][1].view(torch.int16), outs[v][1].view(torch.int16))
+    if not shuffle:  # the second output is relu(out), exactly (what relu_in=1 would apply by the sign of hi)
+        assert torch.equal(unsplit(outs[1][1]), torch.relu(unsplit(outs[1][0])))
 
 
 @pytest.mark.parametrize("s,Cin,Co", [(4, 32, 32), (2, 64, 48)])

@@ -14,50 +14,11 @@
 //     source address (gather + zero halo via per-lane source, as in conv_f32.hip) and to the reads.
 //   * ReLU-on-input uses the sign of hi for both halves (packed 16-bit ops on the fragments).
 //   * epilogue: bias, act, two split residuals, split (hi, lo) store, pixel-shuffle store.
-#include "common.h"
+#include "conv_x3_common.h"
 
 namespace {
 
 constexpr int BK = 32;
-
-struct ConvX3Args {
-    const uint16_t* in;   // [2][B*H*W][Cin]
-    const uint16_t* w;    // [2][Cout][KH*KW*Cin]
-    const float* bias;
-    const uint16_t* res1;  // [2][M][Cout] or null
-    const uint16_t* res2;
-    const uint16_t* zero;
-    uint16_t* out;         // [2][Mout][Co]
-    long long in_plane, w_plane, out_plane;
-    int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, M;
-    int relu_in, act, shuffle, Co;
-};
-
-__device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
-
-__device__ __forceinline__ void split_store4(uint16_t* hi_ptr, long long plane, const f32x4& v) {
-    float h[4], l[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        h[j] = bf16_to_f32(f32_to_bf16(v[j]));
-        l[j] = v[j] - h[j];
-    }
-    u32x2 ph = {pack_bf16x2(h[0], h[1]), pack_bf16x2(h[2], h[3])};
-    u32x2 pl = {pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3])};
-    *(u32x2*)hi_ptr = ph;
-    *(u32x2*)(hi_ptr + plane) = pl;
-}
-
-__device__ __forceinline__ f32x4 split_load4(const uint16_t* hi_ptr, long long plane) {
-    const u32x2 ph = *(const u32x2*)hi_ptr;
-    const u32x2 pl = *(const u32x2*)(hi_ptr + plane);
-    f32x4 v;
-    v[0] = __uint_as_float(ph[0] << 16) + __uint_as_float(pl[0] << 16);
-    v[1] = __uint_as_float(ph[0] & 0xffff0000u) + __uint_as_float(pl[0] & 0xffff0000u);
-    v[2] = __uint_as_float(ph[1] << 16) + __uint_as_float(pl[1] << 16);
-    v[3] = __uint_as_float(ph[1] & 0xffff0000u) + __uint_as_float(pl[1] & 0xffff0000u);
-    return v;
-}
 
 // BM x BN tile: 128x{128,64,32} for the big maps; 64x64 for the small grids (19^2 / 37^2: with 128-row tiles only 46-172
 // blocks exist, each a 72-216 step latency-bound K-loop -- 4x more, smaller blocks co-reside and overlap their DMA waits)
@@ -76,7 +37,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvX3Args p) {
     const int ntn = p.Cout / BN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tmi = bid / ntn, tni = bid - tmi * ntn;
-    const int m0 = tmi * BM, n0 = tni * BN;
+    const int m0 = p.m_begin + tmi * BM, n0 = tni * BN;
     const int cpt = p.Cin / BK;
     const int ntaps = p.KH * p.KW;
     const int nk = ntaps * cpt;
@@ -187,60 +148,24 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvX3Args p) {
             }
     }
 
-    // ---- epilogue, staged through LDS (the direct form touched 16 pixel rows x 8 B per wave instruction for each
-    // of: hi store, lo store, and up to four residual plane loads).  Each wave parks its (TM*16) x (TN*16) fp32 tile
-    // (bias added) in its own slice of the idle staging buffer, chunk index XOR row; afterwards a wave instruction
-    // covers whole pixel rows: TN*16 consecutive output channels = 128/64 B per plane, contiguous. ----
-    constexpr int ROWB = TN * 64;              // bytes per staged row (fp32)
-    constexpr int NCH = TN * 4;                // 16-byte chunks per row
-    constexpr int LPR = NCH;                   // lanes per row on the way out
-    constexpr int RPI = 64 / LPR;              // rows per wave instruction
-    __syncthreads();                           // all waves are done with the operand stages
-    char* ws = smem + wave * (TM * 16 * ROWB);
-#pragma unroll
-    for (int n = 0; n < TN; ++n) {
-        const int cb = n0 + wn * (TN * 16) + n * 16 + fq * 4;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bv = *(const f32x4*)(p.bias + (p.shuffle ? cb % p.Co : cb));
-#pragma unroll
-        for (int m = 0; m < TM; ++m) {
-            const int r = m * 16 + fr;
-            *(f32x4*)(ws + r * ROWB + (((n * 4 + fq) ^ (r & (NCH - 1))) << 4)) = acc[n][m] + bv;
-        }
-    }
-    const int orr = lane / LPR, oc = lane % LPR;
-#pragma unroll
-    for (int pass = 0; pass < TM * 16 / RPI; ++pass) {
-        const int r = pass * RPI + orr;
-        f32x4 v = *(const f32x4*)(ws + r * ROWB + ((oc ^ (r & (NCH - 1))) << 4));
-        const int pix = m0 + wm * (TM * 16) + r;
-        if (pix >= p.M) continue;
-        const int cb = n0 + wn * (TN * 16) + oc * 4;
-        if (p.shuffle) {
-            const int sx = pix % p.Wo, t = pix / p.Wo, sy = t % p.Ho, sb = t / p.Ho;
-            const int tapo = cb / p.Co, co = cb - tapo * p.Co;
-            const int kh = tapo / p.shuffle, kw = tapo - kh * p.shuffle;
-            const size_t o = (((size_t)sb * (p.Ho * p.shuffle) + sy * p.shuffle + kh) * (p.Wo * p.shuffle) + sx * p.shuffle + kw) * p.Co + co;
-            split_store4(p.out + o, p.out_plane, v);
-            continue;
-        }
-        if (p.act != UFM_ACT_NONE) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act);
-        }
-        const size_t o = (size_t)pix * p.Cout + cb;
-        if (p.res1) v += split_load4(p.res1 + o, p.out_plane);
-        if (p.res2) v += split_load4(p.res2 + o, p.out_plane);
-        split_store4(p.out + o, p.out_plane, v);
-    }
+    // ---- epilogue, staged through LDS (conv_x3_common.h): each wave parks its tile in its own slice of the idle staging buffer ----
+    __syncthreads();  // all waves are done with the operand stages
+    conv_x3_epilogue<TM, TN>(p, acc, smem + wave * (TM * 16 * TN * 64), m0 + wm * (TM * 16), n0 + wn * (TN * 16), lane);
 }
 
 }  // namespace
 
+static int g_conv_variant = 0;
+// test/tuning hook: 0 = auto, 1 = 128-row kernels only, 2 = 8-phase kernel wherever it is applicable
+extern "C" int ufm_debug_set_conv_variant(int v) {
+    g_conv_variant = v;
+    return UFM_OK;
+}
+
 extern "C" int ufm_conv2d_nhwc_bf16x3(const uint16_t* in, int B, int H, int W, int Cin, const uint16_t* weight, int Cout,
                                       int KH, int KW, int stride, int pad, int relu_in, const float* bias, int act,
                                       const uint16_t* res1, const uint16_t* res2, int shuffle, uint16_t* out,
-                                      const uint16_t* zero_page, void* stream) {
+                                      uint16_t* out_relu, const uint16_t* zero_page, void* stream) {
     UFM_REQUIRE(in && weight && out && zero_page, "ufm_conv2d_nhwc_bf16x3: null pointer");
     UFM_REQUIRE(B > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, "ufm_conv2d_nhwc_bf16x3: bad geometry");
     UFM_REQUIRE(Cin % BK == 0 && Cin > 0, "ufm_conv2d_nhwc_bf16x3: Cin=%d must be a multiple of %d", Cin, BK);
@@ -254,24 +179,49 @@ extern "C" int ufm_conv2d_nhwc_bf16x3(const uint16_t* in, int B, int H, int W, i
         UFM_REQUIRE(Cout % (shuffle * shuffle) == 0, "ufm_conv2d_nhwc_bf16x3: Cout not divisible by shuffle^2");
         Co = Cout / (shuffle * shuffle);
         UFM_REQUIRE(Co % 4 == 0, "ufm_conv2d_nhwc_bf16x3: Co=%d must be a multiple of 4 in shuffle mode", Co);
-        UFM_REQUIRE(!res1 && !res2 && act == UFM_ACT_NONE, "ufm_conv2d_nhwc_bf16x3: shuffle mode supports bias only");
+        UFM_REQUIRE(!res1 && !res2 && !out_relu && act == UFM_ACT_NONE, "ufm_conv2d_nhwc_bf16x3: shuffle mode supports bias only");
     }
     const long long M = (long long)B * Ho * Wo;
     UFM_REQUIRE(M < (1ll << 31), "ufm_conv2d_nhwc_bf16x3: problem too large");
     const long long Mout = shuffle ? M * shuffle * shuffle : M;
-    ConvX3Args p{in, weight, bias, res1, res2, zero_page, out,
+    ConvX3Args p{in, weight, bias, res1, res2, zero_page, out, out_relu,
                  (long long)B * H * W * Cin, (long long)Cout * KH * KW * Cin, Mout * Co,
-                 B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, (int)M, relu_in, act, shuffle, Co};
-    const int ntm = (int)((M + 127) / 128);
-    const long long blocks128 = (long long)ntm * (Cout % 128 == 0 ? Cout / 128 : Cout % 64 == 0 ? Cout / 64 : Cout / 32);
-    if (Cout % 64 == 0 && blocks128 < 400) {  // small grid: 64x64 tiles, several co-resident blocks per CU
-        hipLaunchKernelGGL((conv_x3_kernel<64, 64>), dim3((unsigned)(((M + 63) / 64) * (Cout / 64))), dim3(256), 0, (hipStream_t)stream, p);
-    } else if (Cout % 128 == 0) {
-        hipLaunchKernelGGL((conv_x3_kernel<128, 128>), dim3(ntm * (Cout / 128)), dim3(256), 0, (hipStream_t)stream, p);
-    } else if (Cout % 64 == 0) {
-        hipLaunchKernelGGL((conv_x3_kernel<128, 64>), dim3(ntm * (Cout / 64)), dim3(256), 0, (hipStream_t)stream, p);
+                 B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, (int)M, relu_in, act, shuffle, Co, 0};
+    // Kernel choice.  Cout % 256 == 0 and a grid that fills the chip: the 256x256 8-phase kernel on the leading pixels
+    // that make whole rounds of 256 CUs, the 128-row kernel on the rest (g_conv_variant: 0 auto, 1 = 128-row kernels
+    // only, 2 = 8-phase on everything it accepts -- tests/tools).
+    auto launch128 = [&](const ConvX3Args& q) {
+        const long long Mq = q.M - q.m_begin;
+        const int ntm = (int)((Mq + 127) / 128);
+        const long long blocks128 = (long long)ntm * (Cout % 128 == 0 ? Cout / 128 : Cout % 64 == 0 ? Cout / 64 : Cout / 32);
+        if (Cout % 64 == 0 && blocks128 < 400) {  // small grid: 64x64 tiles, several co-resident blocks per CU
+            hipLaunchKernelGGL((conv_x3_kernel<64, 64>), dim3((unsigned)(((Mq + 63) / 64) * (Cout / 64))), dim3(256), 0, (hipStream_t)stream, q);
+        } else if (Cout % 128 == 0) {
+            hipLaunchKernelGGL((conv_x3_kernel<128, 128>), dim3(ntm * (Cout / 128)), dim3(256), 0, (hipStream_t)stream, q);
+        } else if (Cout % 64 == 0) {
+            hipLaunchKernelGGL((conv_x3_kernel<128, 64>), dim3(ntm * (Cout / 64)), dim3(256), 0, (hipStream_t)stream, q);
+        } else {
+            hipLaunchKernelGGL((conv_x3_kernel<128, 32>), dim3(ntm * (Cout / 32)), dim3(256), 0, (hipStream_t)stream, q);
+        }
+    };
+    const bool ok8 = Cout % 256 == 0 && KH * KW * (Cin / 32) >= 2 && p.in_plane < (1ll << 31) && p.w_plane < (1ll << 31);
+    const long long t256 = ((M + 255) / 256) * (Cout / 256);
+    if (ok8 && g_conv_variant == 2) {
+        ufm_launch_conv_x3_8ph(p, (hipStream_t)stream);
+    } else if (ok8 && g_conv_variant == 0 && t256 >= 256) {
+        const long long full = t256 / 256;                          // whole rounds of the 8-phase kernel
+        const long long m_main = full * 256 / (Cout / 256) * 256;   // leading pixels whose tiles fit in them
+        if (m_main >= M) {
+            ufm_launch_conv_x3_8ph(p, (hipStream_t)stream);
+        } else {
+            ConvX3Args lead = p, rest = p;
+            lead.M = (int)m_main;
+            rest.m_begin = (int)m_main;
+            ufm_launch_conv_x3_8ph(lead, (hipStream_t)stream);
+            launch128(rest);
+        }
     } else {
-        hipLaunchKernelGGL((conv_x3_kernel<128, 32>), dim3(ntm * (Cout / 32)), dim3(256), 0, (hipStream_t)stream, p);
+        launch128(p);
     }
     UFM_CHECK_LAUNCH("ufm_conv2d_nhwc_bf16x3");
     return UFM_OK;

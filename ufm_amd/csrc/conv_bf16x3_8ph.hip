@@ -1,0 +1,223 @@
+// 256 px x 256 cout x 32 ch "8-phase" bf16x3 implicit-GEMM convolution: the schedule of gemm_bf16_8ph.hip (ping-pong
+// wave groups, counted vmcnt, four half-tiles in flight, no vmcnt(0)/__syncthreads in the loop) applied to the
+// split-precision convolution of conv_bf16x3.hip.  Same arithmetic in the same order (K-tile = 32 channels of one
+// filter tap, channel-chunk major / tap inner; per K-tile wl*ah, wh*al, wh*ah), so its results are BIT-IDENTICAL
+// to conv_x3_kernel's -- the parity test checks exactly that.
+//
+// What changes against the GEMM form:
+//   * a half-tile is [2 planes (hi, lo)][128 rows][64 B] = 16 KiB: the two planes play the role of the GEMM's two
+//     32-deep k-substeps, a phase is 8 x 3 = 24 MFMA, and the reads per phase stay 8 / 4 / 8 / 4 ds_read_b128;
+//   * a wave's two DMA pieces of a half-tile are the hi and lo plane of the same 16 rows; the A rows are gathered
+//     (output pixel + filter tap, halo from the zero page) through the per-lane source address;
+//   * 64-B LDS rows: 16-byte chunk index XOR g[(row >> 2) & 3], g = {0,2,3,1} (conv_bf16x3.hip);
+//   * Cout = 256 is ONE column tile: every input pixel is gathered once (the 128x128 kernel gathers it twice).
+#include "conv_x3_common.h"
+
+namespace {
+
+constexpr int HALF = 2 * 128 * 64;  // 16 KiB half-tile: [plane][128 rows][64 B]
+constexpr int PLANE = 128 * 64;
+
+template <int K>
+using IC = std::integral_constant<int, K>;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+struct TapIter {  // walks the K-tiles of one half-tile kind: channel-chunk outer, filter tap inner
+    int tap, kh, kw, c0;
+};
+
+__global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
+    __shared__ __attribute__((aligned(16))) char smem[8 * HALF];  // [tile & 1][kind]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int ntn = p.Cout >> 8;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tmi = bid / ntn, tni = bid - tmi * ntn;
+    const int m0 = p.m_begin + (tmi << 8), n0 = tni << 8;
+    const int ntaps = p.KH * p.KW;
+    const int nt = ntaps * (p.Cin >> 5);
+    const unsigned ktot = (unsigned)(ntaps * p.Cin);
+
+    // ---- DMA sources.  Wave w stages rows [16w, 16w+16) of every half-tile, hi and lo plane ----
+    const int srow = lane >> 2, slot = lane & 3;
+    const int lr = wave * 16 + srow;
+    const unsigned chunk = (unsigned)((slot ^ swz(lr)) * 8);
+    int x_iy0[2], x_ix0[2];
+    unsigned x_img[2], w_src[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int brow = (lr >> 6) * 128 + h * 64 + (lr & 63);  // X half h: pixel rows mh = h of both wave groups
+        const int m = min(m0 + brow, p.M - 1);
+        const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
+        x_iy0[h] = oy * p.stride - p.pad;
+        x_ix0[h] = ox * p.stride - p.pad;
+        x_img[h] = (unsigned)b * (unsigned)(p.H * p.W);
+        const int bcol = (lr >> 5) * 64 + h * 32 + (lr & 31);   // W half h: couts nh = h of the four wave columns
+        w_src[h] = (unsigned)(n0 + bcol) * ktot + chunk;
+    }
+    TapIter it[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    auto stage = [&](auto kind, int tile) {  // kind: 0 W-lo, 1 X-lo, 2 W-hi, 3 X-hi ; issues this kind's NEXT K-tile
+        constexpr int KIND = decltype(kind)::value;
+        constexpr int H = KIND >> 1;
+        TapIter& ti = it[KIND];
+        char* dst = smem + ((tile & 1) * 4 + KIND) * HALF + wave * 1024;
+        const uint16_t *src, *src_lo;
+        if (KIND & 1) {
+            const int iy = x_iy0[H] + ti.kh, ix = x_ix0[H] + ti.kw;
+            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            src = ok ? p.in + ((x_img[H] + (unsigned)(iy * p.W + ix)) * (unsigned)p.Cin + (unsigned)ti.c0 + chunk) : p.zero + chunk;
+            src_lo = ok ? src + p.in_plane : src;
+        } else {
+            src = p.w + (w_src[H] + (unsigned)(ti.tap * p.Cin + ti.c0));
+            src_lo = src + p.w_plane;
+        }
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src_lo), LDS_PTR(dst + PLANE), 16, 0, 0);
+        if (++ti.kw == p.KW) ti.kw = 0, ++ti.kh;
+        if (++ti.tap == ntaps) ti.tap = 0, ti.kh = 0, ti.kw = 0, ti.c0 += 32;
+    };
+
+    // ---- fragment read offsets (16x16x32: lane (fr, fq) reads row fr, 16-byte chunk fq) ----
+    const int fr = lane & 15, fq = lane >> 4;
+    int x_off[4], w_off[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = wr * 64 + i * 16 + fr;
+        x_off[i] = r * 64 + ((fq ^ swz(r)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = wc * 32 + j * 16 + fr;
+        w_off[j] = r * 64 + ((fq ^ swz(r)) << 4);
+    }
+
+    f32x4 acc[2][4][4];  // [mh][n][m]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[h][n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 xf[4][2], wa[2][2], wb[2][2];  // [frag][plane]
+
+    auto read_x = [&](int tile, int mh) {
+        const char* s = smem + ((tile & 1) * 4 + 1 + 2 * mh) * HALF;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            xf[i][0] = *(const bf16x8*)(s + x_off[i]);
+            xf[i][1] = *(const bf16x8*)(s + PLANE + x_off[i]);
+        }
+    };
+    auto read_w = [&](bf16x8 (&w)[2][2], int tile, int nh) {
+        const char* s = smem + ((tile & 1) * 4 + 2 * nh) * HALF;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            w[j][0] = *(const bf16x8*)(s + w_off[j]);
+            w[j][1] = *(const bf16x8*)(s + PLANE + w_off[j]);
+        }
+    };
+    auto mma = [&](auto mh_, auto nh_, bf16x8 (&w)[2][2], bool fresh_x) {
+        constexpr int MH = decltype(mh_)::value, NH = decltype(nh_)::value;
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (fresh_x && p.relu_in) {  // ReLU on the input: the sign of hi decides for both halves
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16x8 neg = xf[i][0] >> 15;
+                xf[i][0] &= ~neg;
+                xf[i][1] &= ~neg;
+            }
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4& a = acc[MH][NH * 2 + j][i];
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][1], xf[i][0], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][0], xf[i][1], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][0], xf[i][0], a, 0, 0, 0);
+            }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // end of the L slot of phase ph (= 4 * tile + i): issue half-tile ph + 6, wait for half-tile ph + 2, barrier
+    const int nhalf = 4 * nt;
+    auto l_end = [&](int tile, auto i_) {
+        constexpr int I = decltype(i_)::value;
+        const int ph = 4 * tile + I;
+        if (ph + 6 < nhalf) {
+            stage(IC<(I + 2) & 3>{}, tile + (I + 6) / 4);
+            wait_vmcnt<8>();
+        } else {
+            const int inflight = nhalf - ph - 3;  // half-tiles issued after half-tile ph + 2
+            if (inflight >= 3) wait_vmcnt<6>();
+            else if (inflight == 2) wait_vmcnt<4>();
+            else if (inflight == 1) wait_vmcnt<2>();
+            else wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto tile_body = [&](int t, bf16x8 (&wcur)[2][2], bf16x8 (&wnxt)[2][2]) {  // wcur holds W-lo(t) on entry
+        read_x(t, 0);
+        l_end(t, IC<0>{});
+        mma(IC<0>{}, IC<0>{}, wcur, true);
+        read_w(wnxt, t, 1);
+        l_end(t, IC<1>{});
+        mma(IC<0>{}, IC<1>{}, wnxt, false);
+        read_x(t, 1);
+        l_end(t, IC<2>{});
+        mma(IC<1>{}, IC<1>{}, wnxt, true);
+        if (t + 1 < nt) read_w(wnxt, t + 1, 0);  // W-lo of the next K-tile into the set W-hi(t) just vacated
+        l_end(t, IC<3>{});
+        mma(IC<1>{}, IC<0>{}, wcur, false);
+    };
+
+    // ---- prologue: half-tiles 0..5 (host guarantees nt >= 2) ----
+    stage(IC<0>{}, 0);
+    stage(IC<1>{}, 0);
+    stage(IC<2>{}, 0);
+    stage(IC<3>{}, 0);
+    stage(IC<0>{}, 1);
+    stage(IC<1>{}, 1);
+    wait_vmcnt<8>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    read_w(wb, 0, 0);
+    if (wr == 1) {  // stagger: the wr = 1 group runs one slot behind
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    int t = 0;
+    for (; t + 1 < nt; t += 2) {
+        tile_body(t, wb, wa);
+        tile_body(t + 1, wa, wb);
+    }
+    if (t < nt) tile_body(t, wb, wa);
+
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // pairs with the last M-slot barrier of the wr = 1 group
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        conv_x3_epilogue<4, 4>(p, acc[h], smem + wave * 16384, m0 + wr * 128 + h * 64, n0 + wc * 64, lane);
+}
+
+}  // namespace
+
+int ufm_launch_conv_x3_8ph(const ConvX3Args& p, hipStream_t stream) {
+    const int ntm = (p.M - p.m_begin + 255) / 256;
+    hipLaunchKernelGGL(conv_x3_8ph_kernel, dim3(ntm * (p.Cout / 256)), dim3(512), 0, stream, p);
+    return 0;
+}

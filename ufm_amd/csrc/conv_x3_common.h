@@ -1,0 +1,103 @@
+// Shared pieces of the bf16x3 convolution kernels (conv_bf16x3.hip, conv_bf16x3_8ph.hip).
+#pragma once
+#include "common.h"
+
+struct ConvX3Args {
+    const uint16_t* in;   // [2][B*H*W][Cin]
+    const uint16_t* w;    // [2][Cout][KH*KW*Cin]
+    const float* bias;
+    const uint16_t* res1;  // [2][M][Cout] or null
+    const uint16_t* res2;
+    const uint16_t* zero;
+    uint16_t* out;         // [2][Mout][Co]
+    uint16_t* out_relu;    // optional second output: relu(out), same layout (the next RCU conv's input; the raw `out` feeds its skip)
+    long long in_plane, w_plane, out_plane;
+    int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, M;
+    int relu_in, act, shuffle, Co;
+    int m_begin;  // the launch covers output pixels [m_begin, M) (hybrid 8-phase + 128-row split of one conv)
+};
+
+static __device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
+
+static __device__ __forceinline__ void split_store4(uint16_t* hi_ptr, long long plane, const f32x4& v) {
+    float h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[j] = bf16_to_f32(f32_to_bf16(v[j]));
+        l[j] = v[j] - h[j];
+    }
+    u32x2 ph = {pack_bf16x2(h[0], h[1]), pack_bf16x2(h[2], h[3])};
+    u32x2 pl = {pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3])};
+    *(u32x2*)hi_ptr = ph;
+    *(u32x2*)(hi_ptr + plane) = pl;
+}
+
+static __device__ __forceinline__ f32x4 split_load4(const uint16_t* hi_ptr, long long plane) {
+    const u32x2 ph = *(const u32x2*)hi_ptr;
+    const u32x2 pl = *(const u32x2*)(hi_ptr + plane);
+    f32x4 v;
+    v[0] = __uint_as_float(ph[0] << 16) + __uint_as_float(pl[0] << 16);
+    v[1] = __uint_as_float(ph[0] & 0xffff0000u) + __uint_as_float(pl[0] & 0xffff0000u);
+    v[2] = __uint_as_float(ph[1] << 16) + __uint_as_float(pl[1] << 16);
+    v[3] = __uint_as_float(ph[1] & 0xffff0000u) + __uint_as_float(pl[1] & 0xffff0000u);
+    return v;
+}
+
+
+// Epilogue of one wave's (TM*16) x (TN*16) fp32 tile, staged through `ws` (TM*16 rows x TN*64 B of LDS owned by the
+// wave).  The direct form touched 16 pixel rows x 8 B per wave instruction for each of: hi store, lo store, and up to
+// four residual plane loads; staged, a wave instruction covers whole pixel rows (TN*16 consecutive output channels =
+// 128/64 B per plane, contiguous).  Chunk index XOR row keeps both the accumulator-shaped writes and the row-shaped
+// reads conflict-free.  LDS ops of one wave execute in order: no barrier between the writes and the reads.
+template <int TM, int TN>
+static __device__ __forceinline__ void conv_x3_epilogue(const ConvX3Args& p, f32x4 (&acc)[TN][TM], char* ws, int pix0, int cb0, int lane) {
+    constexpr int ROWB = TN * 64;              // bytes per staged row (fp32)
+    constexpr int NCH = TN * 4;                // 16-byte chunks per row
+    constexpr int LPR = NCH;                   // lanes per row on the way out
+    constexpr int RPI = 64 / LPR;              // rows per wave instruction
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+        const int cb = cb0 + n * 16 + fq * 4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = *(const f32x4*)(p.bias + (p.shuffle ? cb % p.Co : cb));
+#pragma unroll
+        for (int m = 0; m < TM; ++m) {
+            const int r = m * 16 + fr;
+            *(f32x4*)(ws + r * ROWB + (((n * 4 + fq) ^ (r & (NCH - 1))) << 4)) = acc[n][m] + bv;
+        }
+    }
+    const int orr = lane / LPR, oc = lane % LPR;
+#pragma unroll
+    for (int pass = 0; pass < TM * 16 / RPI; ++pass) {
+        const int r = pass * RPI + orr;
+        f32x4 v = *(const f32x4*)(ws + r * ROWB + ((oc ^ (r & (NCH - 1))) << 4));
+        const int pix = pix0 + r;
+        if (pix >= p.M) continue;
+        const int cb = cb0 + oc * 4;
+        if (p.shuffle) {
+            const int sx = pix % p.Wo, t = pix / p.Wo, sy = t % p.Ho, sb = t / p.Ho;
+            const int tapo = cb / p.Co, co = cb - tapo * p.Co;
+            const int kh = tapo / p.shuffle, kw = tapo - kh * p.shuffle;
+            const size_t o = (((size_t)sb * (p.Ho * p.shuffle) + sy * p.shuffle + kh) * (p.Wo * p.shuffle) + sx * p.shuffle + kw) * p.Co + co;
+            split_store4(p.out + o, p.out_plane, v);
+            continue;
+        }
+        if (p.act != UFM_ACT_NONE) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act);
+        }
+        const size_t o = (size_t)pix * p.Cout + cb;
+        if (p.res1) v += split_load4(p.res1 + o, p.out_plane);
+        if (p.res2) v += split_load4(p.res2 + o, p.out_plane);
+        split_store4(p.out + o, p.out_plane, v);
+        if (p.out_relu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+            split_store4(p.out_relu + o, p.out_plane, v);
+        }
+    }
+}
+
+// conv_bf16x3_8ph.hip: 256 px x 256 cout 8-phase kernel (Cout % 256 == 0, 32-bit operand offsets)
+int ufm_launch_conv_x3_8ph(const ConvX3Args& p, hipStream_t stream);

@@ -18,7 +18,7 @@ template <int OUT_BF16>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ntn = p.N / BN, ntm = (p.M + BM - 1) / BM;
+    const int ntn = p.N / BN, ntm = (p.M - p.m_begin + BM - 1) / BM;
     // XCD chunking + grouped rasterization: 64 consecutive logical tiles (what one XCD runs at a time) cover
     // 8 M-panels x 8 N-panels, so each A and W panel is re-used 8x out of that XCD's L2 (N-fastest order
     // streamed W from beyond L2 once per M-panel: 622 MB fetched for 51 MB of operands, PMC FETCH_SIZE)
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     const int grp = bid / per_group, in_g = bid - grp * per_group;
     const int gm = min(GM, ntm - grp * GM);
     const int tm = grp * GM + in_g % gm, tn = in_g / gm;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = p.m_begin + tm * BM, n0 = tn * BN;
     const int nk = p.K / BK;
 
     // ---- staging addresses: wave w issues DMA pieces 4w..4w+3 of each operand tile; piece = 8 rows ----
@@ -350,24 +350,56 @@ extern "C" int ufm_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int 
     UFM_REQUIRE(ldo % 4 == 0 && ldo >= N && (!res || (ldres % 4 == 0 && ldres >= N)), "ufm_gemm_bf16: bad ldo/ldres");
     UFM_REQUIRE(out_dtype == UFM_F32 || out_dtype == UFM_BF16, "ufm_gemm_bf16: bad out_dtype %d", out_dtype);
     UFM_REQUIRE((size_t)M * (size_t)(lda > ldo ? lda : ldo) < (1ull << 40), "ufm_gemm_bf16: problem too large");
-    GemmArgs p{A, W, bias, gamma, res, out, lda, ldw, M, N, K, act, ldres, res_row_mod, ldo, out_row_group, g_force_small >= 20 ? g_force_small - 20 : (g_force_small >= 10 ? g_force_small - 10 : 0)};
-    // Kernel choice.  The persistent 256xBN kernels (DMA ring across tiles) are kept as opt-in variants 2/3:
-    // they are correct (tests/test_kernels_gpu.py) but measured 5-30 % SLOWER than the 128x128 kernel on the
-    // UFM shapes -- two independent co-resident blocks per CU overlap DMA waits, epilogues and MFMA phases
-    // better than a single hand-pipelined block.
+    GemmArgs p{A, W, bias, gamma, res, out, lda, ldw, M, N, K, act, ldres, res_row_mod, ldo, out_row_group,
+               g_force_small >= 20 ? g_force_small - 20 : (g_force_small >= 10 ? g_force_small - 10 : 0), 0};
     constexpr int NCU = 256;
     const int ntm256 = (M + PBM - 1) / PBM;
     const int t256 = (N % 256 == 0) ? ntm256 * (N / 256) : 0;
     const int t128 = ntm256 * (N / 128);
-    int variant = g_force_small >= 20 ? 1 : (g_force_small >= 10 ? 3 : g_force_small);  // 0 auto, 1 = 128x128, 2 = persistent BN=128, 3 = persistent BN=256
-    // auto: the 256x256 8-phase kernel where it measured faster (tools/gemm_ab.py, profiles/r01/gemm_ab.log): wide-N
-    // linears; the 128x128 kernel (two co-resident blocks per CU) for N < 1024 and short K, where its finer tiles win
-    if (variant == 0) variant = (t256 > 0 && N >= 1024 && K >= 512) ? 4 : 1;
-    if (variant == 3 && t256 == 0) variant = 2;
+    // variant: 0 auto, 1 = 128x128, 2 = persistent 256x128, 3 = persistent 256x256, 4 = 256x256 8-phase,
+    //          5 = hybrid (8-phase on the leading rows that fill whole rounds of 256 CUs, 128x128 on the rest)
+    int variant = g_force_small >= 20 ? 1 : (g_force_small >= 10 ? 3 : g_force_small);
     const bool fits32 = (long long)M * lda < (1ll << 31) && (long long)N * ldw < (1ll << 31);
+    const bool ok8 = t256 > 0 && K >= 128 && fits32;
+    int m_split = 0;  // rows [0, m_split) -> 8-phase kernel, [m_split, M) -> 128x128 kernel
+    if (variant == 0 || variant == 5) {
+        // Cost model in units of one 8-phase tile (T4): a round of the 128x128 kernel (512 co-resident tiles of a
+        // quarter of the work) measured 0.62 T4, a second launch ~0.1 T4 (tools/gemm_ab.py, profiles/r01/gemm_ab_*.log).
+        // The 8-phase kernel only where it measured faster at all: wide N, K >= 512.
+        const int ntn = N / 256;
+        auto rounds1 = [&](int rows) { return rows <= 0 ? 0.0 : 0.62 * (double)(((long long)((rows + 127) / 128) * (N / 128) + 511) / 512); };
+        double best = rounds1(M);
+        int best_variant = 1;
+        if (ok8 && ((N >= 1024 && K >= 512) || (N >= 768 && K >= 2048) || variant == 5)) {
+            const double c4 = (double)((t256 + NCU - 1) / NCU);
+            if (c4 < best) best = c4, best_variant = 4;
+            const int full = t256 / NCU;                   // whole rounds of the 8-phase kernel
+            const int rows_main = full * NCU / ntn * 256;  // leading rows whose tiles fit in them
+            if (full > 0 && rows_main < M) {
+                const double c5 = full + rounds1(M - rows_main) + 0.1;
+                if (c5 < best || variant == 5) best = c5, best_variant = 5, m_split = rows_main;
+            }
+        }
+        variant = (variant == 5 && best_variant != 5) ? (ok8 ? 4 : 1) : best_variant;
+    }
+    if ((variant == 4 || variant == 5) && !ok8) variant = 1;
+    if (variant == 3 && t256 == 0) variant = 2;
     if (!fits32) variant = 1;
-    if (variant == 4 && (t256 == 0 || K < 128)) variant = 1;
-    if (variant == 4) {
+    auto launch128 = [&](const GemmArgs& q) {
+        const int ntm = (q.M - q.m_begin + BM - 1) / BM, ntn = N / BN;
+        dim3 grid(ntm * ntn), block(256);
+        if (out_dtype == UFM_BF16)
+            hipLaunchKernelGGL(gemm_bf16_kernel<1>, grid, block, 0, (hipStream_t)stream, q);
+        else
+            hipLaunchKernelGGL(gemm_bf16_kernel<0>, grid, block, 0, (hipStream_t)stream, q);
+    };
+    if (variant == 5) {
+        GemmArgs lead = p, rest = p;
+        lead.M = m_split;
+        rest.m_begin = m_split;
+        ufm_launch_gemm_8ph(lead, out_dtype, (hipStream_t)stream);
+        launch128(rest);
+    } else if (variant == 4) {
         ufm_launch_gemm_8ph(p, out_dtype, (hipStream_t)stream);
     } else if (variant == 3) {
         dim3 grid(t256 < NCU ? t256 : NCU), block(512);
@@ -382,12 +414,7 @@ extern "C" int ufm_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int 
         else
             hipLaunchKernelGGL((gemm_bf16_persistent<128, 0>), grid, block, 0, (hipStream_t)stream, p);
     } else {
-        const int ntm = (M + BM - 1) / BM, ntn = N / BN;
-        dim3 grid(ntm * ntn), block(256);
-        if (out_dtype == UFM_BF16)
-            hipLaunchKernelGGL(gemm_bf16_kernel<1>, grid, block, 0, (hipStream_t)stream, p);
-        else
-            hipLaunchKernelGGL(gemm_bf16_kernel<0>, grid, block, 0, (hipStream_t)stream, p);
+        launch128(p);
     }
     UFM_CHECK_LAUNCH("ufm_gemm_bf16");
     return UFM_OK;

@@ -39,13 +39,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_8ph_kernel(GemmArgs p) {
     const int wr = wave >> 2, wc = wave & 3;
 
     // ---- tile of this block: XCD chunking + grouped rasterization (as gemm_bf16.hip) ----
-    const int ntn = p.N >> 8, ntm = (p.M + 255) >> 8;
+    const int ntn = p.N >> 8, ntm = (p.M - p.m_begin + 255) >> 8;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     constexpr int GM = 4;
     const int per_group = GM * ntn;
     const int grp = bid / per_group, in_g = bid - grp * per_group;
     const int gm = min(GM, ntm - grp * GM);
-    const int m0 = (grp * GM + in_g % gm) << 8, n0 = (in_g / gm) << 8;
+    const int m0 = p.m_begin + ((grp * GM + in_g % gm) << 8), n0 = (in_g / gm) << 8;
     const int nt = p.K >> 6;
 
     // ---- DMA source offsets (elements).  Wave w issues pieces w and 8+w of every half-tile; piece = 8 rows ----
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_8ph_kernel(GemmArgs p) {
 }  // namespace
 
 int ufm_launch_gemm_8ph(const GemmArgs& p, int out_dtype, hipStream_t stream) {
-    const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
+    const int ntm = (p.M - p.m_begin + 255) / 256, ntn = p.N / 256;
     dim3 grid(ntm * ntn), block(512);
     if (out_dtype == UFM_BF16)
         hipLaunchKernelGGL(gemm_bf16_8ph_kernel<1>, grid, block, 0, stream, p);

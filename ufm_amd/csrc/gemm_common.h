@@ -11,7 +11,8 @@ struct GemmArgs {
     void* out;
     int lda, ldw, M, N, K;
     int act, ldres, res_row_mod, ldo, out_row_group;
-    int debug;  // diagnostics only (tools/): 1 = every block reads tile (0,0), 2 = no DMA
+    int debug;    // diagnostics only (tools/): 1 = every block reads tile (0,0), 2 = no DMA
+    int m_begin;  // the launch covers rows [m_begin, M) (hybrid 256x256 + 128x128 split of one GEMM); row indices stay absolute
 };
 
 namespace {

@@ -265,9 +265,12 @@ class Engine:
             assert res_row_mod == 0 and out_row_group == 0 and out.dtype == torch.float32
             hip.conv2d(x, 1, 1, M, lin.k, lin.w, lin.n, 1, 1, 1, 0, out, self.zero, bias=lin.b, act=act, gamma=gamma, res1=res)
 
-    def conv(self, x, B, H, W, c: _Conv, out, *, relu_in=False, act=hip.ACT_NONE, res1=None, res2=None):
-        fn = hip.conv2d_x3 if c.w.dtype == torch.bfloat16 else hip.conv2d
-        fn(x, B, H, W, c.cin, c.w, c.cout, c.k, c.k, c.stride, c.pad, out, self.zero, relu_in=relu_in, bias=c.b, act=act, res1=res1, res2=res2, shuffle=c.shuffle)
+    def conv(self, x, B, H, W, c: _Conv, out, *, relu_in=False, act=hip.ACT_NONE, res1=None, res2=None, out_relu=None):
+        if c.w.dtype == torch.bfloat16:
+            hip.conv2d_x3(x, B, H, W, c.cin, c.w, c.cout, c.k, c.k, c.stride, c.pad, out, self.zero, relu_in=relu_in, bias=c.b, act=act, res1=res1, res2=res2, shuffle=c.shuffle, out_relu=out_relu)
+        else:
+            assert out_relu is None
+            hip.conv2d(x, B, H, W, c.cin, c.w, c.cout, c.k, c.k, c.stride, c.pad, out, self.zero, relu_in=relu_in, bias=c.b, act=act, res1=res1, res2=res2, shuffle=c.shuffle)
 
     def hbuf(self, name: str, shape: Tuple[int, ...]) -> torch.Tensor:
         """Head activation buffer: fp32 [shape] or the split format (2, *shape) bf16."""
@@ -328,15 +331,25 @@ class Engine:
                 u = self.hbuf(f"{tag}_post{i}", (B, sizes[i][0], sizes[i][1], ld[i]))
                 self.conv(t, B, gh, gw, hw.act[i][1], u)
             ri = self.hbuf(f"{tag}_rn{i}", (B, sizes[i][0], sizes[i][1], Fd))
-            self.conv(u, B, sizes[i][0], sizes[i][1], hw.rn[i], ri)
-            r.append(ri)
+            # split mode: the producer of an RCU input also writes relu(x) (ufm_conv2d_nhwc_bf16x3 out_relu), which takes
+            # the ReLU out of the consumer's MFMA loop; the fp32 kernels apply it on their fragments (relu_in)
+            rr = self.hbuf(f"{tag}_rn{i}_relu", (B, sizes[i][0], sizes[i][1], Fd)) if self.head_split else None
+            self.conv(u, B, sizes[i][0], sizes[i][1], hw.rn[i], ri, out_relu=rr)
+            r.append((ri, rr))
 
-        def rcu(x, pair, h, w, name, extra_res=None):
+        def rcu(xs, pair, h, w, name, extra_res=None, want_relu=False):
+            """[U] ResidualConvUnit: conv2(relu(conv1(relu(x)))) + x (+ extra_res).  xs = (x, relu(x) or None)."""
+            x, xr = xs
             t1 = self.hbuf(f"{tag}_{name}_t", (B, h, w, Fd))
             o = self.hbuf(f"{tag}_{name}_o", (B, h, w, Fd))
-            self.conv(x, B, h, w, pair[0], t1, relu_in=True)
-            self.conv(t1, B, h, w, pair[1], o, relu_in=True, res1=x, res2=extra_res)
-            return o
+            orl = self.hbuf(f"{tag}_{name}_or", (B, h, w, Fd)) if (want_relu and self.head_split) else None
+            if self.head_split:
+                self.conv(xr, B, h, w, pair[0], t1, act=hip.ACT_RELU)  # relu applied once, by the producers
+                self.conv(t1, B, h, w, pair[1], o, res1=x, res2=extra_res, out_relu=orl)
+            else:
+                self.conv(x, B, h, w, pair[0], t1, relu_in=True)
+                self.conv(t1, B, h, w, pair[1], o, relu_in=True, res1=x, res2=extra_res)
+            return (o, orl)
 
         path = None
         for lvl in (3, 2, 1, 0):
@@ -345,8 +358,8 @@ class Engine:
             if path is None:
                 s = r[lvl]
             else:
-                s = rcu(r[lvl], f["r1"], h, w, f"f{lvl}a", extra_res=path)  # path + resConfUnit1(r)
-            o = rcu(s, f["r2"], h, w, f"f{lvl}b")
+                s = rcu(r[lvl], f["r1"], h, w, f"f{lvl}a", extra_res=path, want_relu=True)  # path + resConfUnit1(r)
+            o, _ = rcu(s, f["r2"], h, w, f"f{lvl}b")
             # out_conv (1x1) commutes with the bilinear x2 (weights sum to 1): run it at low resolution
             c = self.hbuf(f"{tag}_f{lvl}c", (B, h, w, Fd))
             self.conv(o, B, h, w, f["out"], c)
