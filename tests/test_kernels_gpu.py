@@ -78,6 +78,33 @@ def test_gemm_bf16(hip, M, N, K, act, use_gamma, use_res, out_bf16, row_mod, row
     assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("variant", [1, 4])
+def test_gemm_gelu_epilogue_accuracy(hip, variant):
+    """The bf16-output GELU epilogue (gelu_bf16_x4: relu(x) - |x| 2^-g(|x|), one transcendental per value) against
+    the exact erf form: after rounding to bf16 the result must equal bf16(exact) except for rare 1-ulp flips at
+    rounding boundaries, over the whole bf16 grid in [-9, 9] incl. the negative tail."""
+    lib = hip.lib()
+    xs = torch.arange(-9.0, 9.0, 1.0 / 64).to(torch.bfloat16).unique().float()  # bf16-representable inputs
+    M, N, K = xs.numel(), 256, 128
+    A = torch.zeros(M, K)
+    A[:, 0] = xs
+    W = torch.zeros(N, K)
+    W[:, 0] = 1.0
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    lib.ufm_debug_set_gemm_variant(variant)
+    try:
+        hip.gemm_bf16(A.to(DEV).bfloat16(), W.to(DEV).bfloat16(), M, N, K, out, act=1)
+    finally:
+        lib.ufm_debug_set_gemm_variant(0)
+    got = out.cpu()
+    want = F.gelu(xs.double()).to(torch.bfloat16)[:, None].expand(M, N)
+    ulps = (got.view(torch.int16).int() - want.contiguous().view(torch.int16).int()).abs()
+    fit = (xs >= -6.0)[:, None].expand(M, N)  # below -6 the kernel holds Phi at Phi(-6) = 1e-9: |gelu| < 1e-8 either way
+    assert ulps[fit].max().item() <= 1, ulps[fit].max().item()
+    assert (ulps[fit] == 0).float().mean().item() >= 0.99
+    assert (got.float() - want.float())[~fit].abs().max().item() <= 2e-8
+
+
 @pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 28])
 @pytest.mark.parametrize("M,N,K,out_bf16", [(256 * 70 + 13, 768, 192, True), (256 * 64 + 200, 1024, 640, False)])
 def test_gemm_large_tile_variants(hip, variant, M, N, K, out_bf16):

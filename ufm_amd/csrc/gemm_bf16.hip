@@ -351,14 +351,14 @@ extern "C" int ufm_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int 
     UFM_REQUIRE(out_dtype == UFM_F32 || out_dtype == UFM_BF16, "ufm_gemm_bf16: bad out_dtype %d", out_dtype);
     UFM_REQUIRE((size_t)M * (size_t)(lda > ldo ? lda : ldo) < (1ull << 40), "ufm_gemm_bf16: problem too large");
     GemmArgs p{A, W, bias, gamma, res, out, lda, ldw, M, N, K, act, ldres, res_row_mod, ldo, out_row_group,
-               g_force_small >= 20 ? g_force_small - 20 : (g_force_small >= 10 ? g_force_small - 10 : 0), 0};
+               g_force_small >= 40 ? g_force_small - 40 : g_force_small >= 20 ? g_force_small - 20 : (g_force_small >= 10 ? g_force_small - 10 : 0), 0};
     constexpr int NCU = 256;
     const int ntm256 = (M + PBM - 1) / PBM;
     const int t256 = (N % 256 == 0) ? ntm256 * (N / 256) : 0;
     const int t128 = ntm256 * (N / 128);
     // variant: 0 auto, 1 = 128x128, 2 = persistent 256x128, 3 = persistent 256x256, 4 = 256x256 8-phase,
     //          5 = hybrid (8-phase on the leading rows that fill whole rounds of 256 CUs, 128x128 on the rest)
-    int variant = g_force_small >= 20 ? 1 : (g_force_small >= 10 ? 3 : g_force_small);
+    int variant = g_force_small >= 40 ? 4 : g_force_small >= 20 ? 1 : (g_force_small >= 10 ? 3 : g_force_small);
     const bool fits32 = (long long)M * lda < (1ll << 31) && (long long)N * ldw < (1ll << 31);
     const bool ok8 = t256 > 0 && K >= 128 && fits32;
     int m_split = 0;  // rows [0, m_split) -> 8-phase kernel, [m_split, M) -> 128x128 kernel

@@ -184,6 +184,17 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_8ph_kernel(GemmArgs p) {
     __builtin_amdgcn_sched_barrier(0);
     // every wave has passed its last ds_read and every DMA has landed (the tail waits end at vmcnt(0)):
     // the staging buffers are free for the epilogue, 16 KiB per wave, two 64x64 passes
+    if (p.debug & 4) {  // ablation (tools/): no epilogue traffic; keep the accumulators live
+        float keep = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) keep += acc[h][n][m][0] + acc[h][n][m][1] + acc[h][n][m][2] + acc[h][n][m][3];
+        if (keep == 123.456f) ((float*)p.out)[0] = keep;
+        return;
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h)
         epilogue_lds<OUT_BF16>(p, acc[h], smem + wave * 16384, m0 + wr * 128 + h * 64, n0 + wc * 64, lane);
