@@ -194,7 +194,9 @@ extern "C" int ufm_conv2d_nhwc_bf16x3(const uint16_t* in, int B, int H, int W, i
         const long long Mq = q.M - q.m_begin;
         const int ntm = (int)((Mq + 127) / 128);
         const long long blocks128 = (long long)ntm * (Cout % 128 == 0 ? Cout / 128 : Cout % 64 == 0 ? Cout / 64 : Cout / 32);
-        if (Cout % 64 == 0 && blocks128 < 400) {  // small grid: 64x64 tiles, several co-resident blocks per CU
+        // small grid: 64x64 tiles, several co-resident blocks per CU.  Threshold from an end-to-end sweep (400 / 200 / 100:
+        // 189.6 / 196.6 / 197.2 pairs/s with two micro-batches): at 128..400 blocks the 128-row tiles win
+        if (Cout % 64 == 0 && blocks128 < 128) {
             hipLaunchKernelGGL((conv_x3_kernel<64, 64>), dim3((unsigned)(((Mq + 63) / 64) * (Cout / 64))), dim3(256), 0, (hipStream_t)stream, q);
         } else if (Cout % 128 == 0) {
             hipLaunchKernelGGL((conv_x3_kernel<128, 128>), dim3(ntm * (Cout / 128)), dim3(256), 0, (hipStream_t)stream, q);
@@ -211,7 +213,7 @@ extern "C" int ufm_conv2d_nhwc_bf16x3(const uint16_t* in, int B, int H, int W, i
     } else if (ok8 && g_conv_variant == 0 && t256 >= 256) {
         const long long full = t256 / 256;                          // whole rounds of the 8-phase kernel
         const long long m_main = full * 256 / (Cout / 256) * 256;   // leading pixels whose tiles fit in them
-        if (m_main >= M) {
+        if (m_main >= M || full == 0) {
             ufm_launch_conv_x3_8ph(p, (hipStream_t)stream);
         } else {
             ConvX3Args lead = p, rest = p;

@@ -32,8 +32,7 @@ template <int K>
 using IC = std::integral_constant<int, K>;
 
 template <int OUT_BF16>
-__global__ __launch_bounds__(512, 1) void gemm_bf16_8ph_kernel(GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[8 * HALF];  // [tile & 1][kind]
+__device__ __forceinline__ void gemm_bf16_8ph_body(const GemmArgs& p, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -59,8 +58,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_8ph_kernel(GemmArgs p) {
         for (int h = 0; h < 2; ++h) {
             const int brow = (lr >> 6) * 128 + h * 64 + (lr & 63);  // X half h: rows mh = h of both wave groups
             const int bcol = (lr >> 5) * 64 + h * 32 + (lr & 31);   // W half h: columns nh = h of the four wave columns
-            xsrc[h][i] = (unsigned)min(m0 + brow, p.M - 1) * (unsigned)p.lda + chunk;
-            wsrc[h][i] = (unsigned)(n0 + bcol) * (unsigned)p.ldw + chunk;
+            xsrc[h][i] = 2u * ((unsigned)min(m0 + brow, p.M - 1) * (unsigned)p.lda + chunk);  // BYTE offsets: the DMA
+            wsrc[h][i] = 2u * ((unsigned)(n0 + bcol) * (unsigned)p.ldw + chunk);               // address is sgpr base + vgpr32
         }
     }
     auto stage = [&](auto kind, int tile) {  // kind: 0 W-lo, 1 X-lo, 2 W-hi, 3 X-hi
@@ -68,8 +67,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_8ph_kernel(GemmArgs p) {
         char* dst = smem + ((tile & 1) * 4 + KIND) * HALF + wave * 1024;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const uint16_t* src = (KIND & 1) ? p.A + xsrc[KIND >> 1][i] : p.W + wsrc[KIND >> 1][i];
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + tile * 64), LDS_PTR(dst + i * 8192), 16, 0, 0);
+            const char* base = (KIND & 1) ? (const char*)p.A : (const char*)p.W;
+            const unsigned off = ((KIND & 1) ? xsrc[KIND >> 1][i] : wsrc[KIND >> 1][i]) + (unsigned)tile * 128u;
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(base + off), LDS_PTR(dst + i * 8192), 16, 0, 0);
         }
     };
 
@@ -200,14 +200,23 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_8ph_kernel(GemmArgs p) {
         epilogue_lds<OUT_BF16>(p, acc[h], smem + wave * 16384, m0 + wr * 128 + h * 64, n0 + wc * 64, lane);
 }
 
+__global__ __launch_bounds__(512, 1) void gemm_bf16_8ph_kernel_bf16(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[8 * HALF];  // [tile & 1][kind]
+    gemm_bf16_8ph_body<1>(p, smem);
+}
+__global__ __launch_bounds__(512, 1) void gemm_bf16_8ph_kernel_f32(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[8 * HALF];
+    gemm_bf16_8ph_body<0>(p, smem);
+}
+
 }  // namespace
 
 int ufm_launch_gemm_8ph(const GemmArgs& p, int out_dtype, hipStream_t stream) {
     const int ntm = (p.M - p.m_begin + 255) / 256, ntn = p.N / 256;
     dim3 grid(ntm * ntn), block(512);
     if (out_dtype == UFM_BF16)
-        hipLaunchKernelGGL(gemm_bf16_8ph_kernel<1>, grid, block, 0, stream, p);
+        hipLaunchKernelGGL(gemm_bf16_8ph_kernel_bf16, grid, block, 0, stream, p);
     else
-        hipLaunchKernelGGL(gemm_bf16_8ph_kernel<0>, grid, block, 0, stream, p);
+        hipLaunchKernelGGL(gemm_bf16_8ph_kernel_f32, grid, block, 0, stream, p);
     return 0;
 }
