@@ -5,7 +5,7 @@ coalesced reads -- MI355X_MICROARCH.md section HBM; WRITE_SIZE is exact for 16-B
 bank-conflict cycles."""
 import collections, csv, glob, json, sys
 out_path = sys.argv[1] if len(sys.argv) > 1 else "profiles/r01/pmc_step_summary.json"
-FAM = {"gemm_bf16_kernel": "ufm_gemm_bf16", "attn_bf16_kernel": "ufm_attention_bf16", "conv_x3_kernel": "ufm_conv2d_nhwc_bf16x3",
+FAM = {"gemm_bf16": "ufm_gemm_bf16", "attn_bf16_kernel": "ufm_attention_bf16", "conv_x3": "ufm_conv2d_nhwc_bf16x3",
        "layernorm_kernel": "ufm_layernorm", "upsample": "ufm_upsample_bilinear_nhwc", "head_tail": "ufm_head_tail",
        "patchify": "ufm_patchify", "unmap": "ufm_unmap", "conv_f32": "ufm_conv2d_nhwc_f32"}
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
