@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--gemm-variant", type=int, default=0, help="tuning hook: ufm_debug_set_gemm_variant (0 = auto)")
+    ap.add_argument("--attn-variant", type=int, default=0, help="tuning hook: ufm_debug_set_attn_variant (0 = default)")
     ap.add_argument("--serial-heads", action="store_true", help="run the two DPT heads on one stream")
     ap.add_argument("--micro-batches", type=int, default=2, help="concurrent micro-batches (HIP streams) per GPU; 1 = single stream")
     args = ap.parse_args()
@@ -86,6 +87,7 @@ def main():
     from ufm_amd.modules import init_weights_
 
     hip.lib().ufm_debug_set_gemm_variant(args.gemm_variant)
+    hip.lib().ufm_debug_set_attn_variant(args.attn_variant)
     res = args.res
     cfg = ufm_amd.ufm_base_config(resolution_wh=(res, res))
     model = ufm_amd.UniFlowMatchConfidence(**cfg).eval()

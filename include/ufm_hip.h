@@ -190,6 +190,17 @@ int ufm_head_tail(const void* x, int in_dtype /* UFM_F32 | UFM_BF16X2 */, int P,
                   const int32_t* kind_host, const float* a_host, const float* d_host, float* out,
                   float* out_logits, void* stream);
 
+/* The whole full-resolution tail of [U] DPTRegressionProcessor in numerics "fast", fused:
+ * bilinear(align_corners=True) (h, w) -> (H, W)  ->  conv 3x3 pad 1 (Cin = 128 -> Cmid = 32) + bias + ReLU  ->
+ * conv 1x1 (32 -> Ct <= 4) + bias  ->  Flow/Mask adaptor (as ufm_head_tail; call sites models/ufm.py:644-660).
+ * in: UFM_BF16X2 [2][B][h][w][128]; w2: UFM_BF16X2 [2][32][3][3][128]; out (and out_logits): fp32 planar
+ * [B][Ct][H][W].  Bit-identical to ufm_upsample_bilinear_nhwc -> ufm_conv2d_nhwc_bf16x3(act = ReLU) ->
+ * ufm_head_tail, without the two full-resolution intermediate maps ever reaching HBM. */
+int ufm_dpt_tail_fused(const uint16_t* in, int B, int h, int w, int Cin, const uint16_t* w2, const float* b2,
+                       int Cmid, int H, int W, const float* wt, const float* bt, int Ct,
+                       const int32_t* kind_host, const float* a_host, const float* d_host, float* out,
+                       float* out_logits, void* stream);
+
 /* =====================================================================================
  * Post-processing (utils/flow_resizing.py:749-877 unmap_predicted_flow and :955-1010
  * unmap_predicted_channels, called from models/base.py:279-332): ROI crop, legacy-nearest

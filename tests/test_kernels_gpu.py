@@ -516,6 +516,37 @@ def test_conv_transpose_bf16x3(hip, s, Cin, Co):
     assert (unsplit(out.cpu()).permute(0, 3, 1, 2) - ref).abs().max().item() <= 4e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("B,h,w,H,W,Ct,kinds", [(2, 21, 19, 37, 33, 2, [0, 0]), (1, 37, 37, 64, 64, 1, [1]), (3, 9, 12, 16, 21, 3, [0, 1, 0])])
+def test_dpt_tail_fused_bit_identical(hip, B, h, w, H, W, Ct, kinds):
+    """ufm_dpt_tail_fused == ufm_upsample_bilinear_nhwc -> ufm_conv2d_nhwc_bf16x3(ReLU) -> ufm_head_tail, bit for bit
+    (ragged tiles, image borders = the conv's zero padding, flow and mask adaptors), and close to the fp64 statement."""
+    x = rnd(B, 128, h, w, seed=1)
+    w2 = rnd(32, 128, 3, 3, seed=2, scale=(128 * 9) ** -0.5)
+    b2 = rnd(32, seed=3, scale=0.1)
+    wt, bt = rnd(Ct, 32, seed=4, scale=0.3), rnd(Ct, seed=5, scale=0.1)
+    a, d = [1.5, 1.0, 0.5][:Ct], [0.25, 0.0, -1.0][:Ct]
+    xs = split(nhwc(x)).to(DEV)
+    w2s = split(w2.permute(0, 2, 3, 1).contiguous()).to(DEV)
+    zero = torch.zeros(256, device=DEV)
+    up = torch.zeros(2, B, H, W, 128, device=DEV, dtype=torch.bfloat16)
+    hip.upsample_bilinear(xs, B, h, w, 128, up, H, W)
+    c2 = torch.zeros(2, B, H, W, 32, device=DEV, dtype=torch.bfloat16)
+    hip.conv2d_x3(up, B, H, W, 128, w2s, 32, 3, 3, 1, 1, c2, zero, bias=b2.to(DEV), act=2)
+    ref_out = torch.full((B, Ct, H, W), 7.0, device=DEV)
+    ref_log = torch.full((B, Ct, H, W), 7.0, device=DEV)
+    hip.head_tail(c2, B * H * W, H * W, 32, wt.to(DEV), bt.to(DEV), Ct, kinds, a, d, ref_out, ref_log)
+    out = torch.full((B, Ct, H, W), 7.0, device=DEV)
+    log = torch.full((B, Ct, H, W), 7.0, device=DEV)
+    hip.dpt_tail_fused(xs, B, h, w, 128, w2s, b2.to(DEV), 32, H, W, wt.to(DEV), bt.to(DEV), Ct, kinds, a, d, out, log)
+    assert torch.equal(out.view(torch.int32), ref_out.view(torch.int32))
+    assert torch.equal(log.view(torch.int32), ref_log.view(torch.int32))
+    y = F.conv2d(F.relu(F.conv2d(F.interpolate(x.double(), size=(H, W), mode="bilinear", align_corners=True), w2.double(), b2.double(), padding=1)),
+                 wt.double()[:, :, None, None], bt.double())
+    for c in range(Ct):
+        want = torch.sigmoid(y[:, c]) if kinds[c] == 1 else y[:, c] * a[c] + d[c]
+        assert (out.cpu()[:, c].double() - want).abs().max().item() <= 1e-4
+
+
 def test_split_format_layernorm_upsample_tail(hip):
     rows, D = 37, 128
     x = rnd(rows, D, seed=1, scale=3.0)

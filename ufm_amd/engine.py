@@ -140,6 +140,7 @@ class Engine:
         self._tls = threading.local()  # .ns = workspace namespace of the micro-batch this thread is running
         self.micro_batches = 2  # >1: the batch is split into micro-batches that run concurrently on separate HIP streams
         self._streams: List[torch.cuda.Stream] = []
+        self.fused_tail = True  # ufm_dpt_tail_fused where the head has the UFM-Base tail shape (bit-identical to the unfused path)
         self.concurrent_heads = False  # measured: no gain on top of the two concurrent micro-batches (166 vs 168 pairs/s)
         self._head_streams: Dict[str, List[torch.cuda.Stream]] = {}
 
@@ -373,13 +374,18 @@ class Engine:
         h8, w8 = 2 * sizes[0][0], 2 * sizes[0][1]
         c1 = self.hbuf(f"{tag}_pc1", (B, h8, w8, hw.p_conv1.cout))
         self.conv(path, B, h8, w8, hw.p_conv1, c1)
-        up = self.hbuf(f"{tag}_up", (B, H, W, hw.p_conv1.cout))
-        hip.upsample_bilinear(c1, B, h8, w8, hw.p_conv1.cout, up, H, W)
-        c2 = self.hbuf(f"{tag}_pc2", (B, H, W, hw.p_conv2a.cout))
-        self.conv(up, B, H, W, hw.p_conv2a, c2, act=hip.ACT_RELU)
         out = torch.empty((B, hw.tail_cout, H, W), device=self.dev, dtype=torch.float32)
         logits = torch.empty_like(out) if 1 in hw.kinds else None
-        hip.head_tail(c2, B * H * W, H * W, hw.tail_cin, hw.tail_w, hw.tail_b, hw.tail_cout, hw.kinds, hw.scale, hw.shift, out, logits)
+        c2a = hw.p_conv2a
+        if self.fused_tail and self.head_split and (c2a.cin, c2a.cout, c2a.k, c2a.stride, c2a.pad, hw.tail_cin) == (128, 32, 3, 1, 1, 32):
+            # upsample -> conv3x3 + ReLU -> conv1x1 -> adaptor in one kernel: the two full-resolution maps stay on chip
+            hip.dpt_tail_fused(c1, B, h8, w8, 128, c2a.w, c2a.b, 32, H, W, hw.tail_w, hw.tail_b, hw.tail_cout, hw.kinds, hw.scale, hw.shift, out, logits)
+        else:
+            up = self.hbuf(f"{tag}_up", (B, H, W, hw.p_conv1.cout))
+            hip.upsample_bilinear(c1, B, h8, w8, hw.p_conv1.cout, up, H, W)
+            c2 = self.hbuf(f"{tag}_pc2", (B, H, W, c2a.cout))
+            self.conv(up, B, H, W, c2a, c2, act=hip.ACT_RELU)
+            hip.head_tail(c2, B * H * W, H * W, hw.tail_cin, hw.tail_w, hw.tail_b, hw.tail_cout, hw.kinds, hw.scale, hw.shift, out, logits)
         res, c0 = {}, 0
         for a in hw.adaptors:
             n = a.required_channels

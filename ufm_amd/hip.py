@@ -33,6 +33,7 @@ SIGNATURES = {
     "ufm_debug_set_gemm_variant": [_i],
     "ufm_debug_set_attn_variant": [_i],
     "ufm_debug_set_conv_variant": [_i],
+    "ufm_dpt_tail_fused": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "ufm_layernorm": [_vp, _i, _vp, _i, _i, _vp, _vp, _f, _vp, _i, _i, _vp],
     "ufm_fill_rows": [_vp, _i, _i, _i, _vp, _i, _vp],
     "ufm_add_rows": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp],
@@ -221,6 +222,12 @@ def upsample_bilinear(x, B, H, W, C, out, Ho, Wo, crop_h=0, crop_w=0):
 
 def head_tail(x, P, HW, Cin, w, b, Cout, kinds, a, d, out, out_logits=None):
     _check(lib().ufm_head_tail(_p(x), BF16X2 if x.dtype == torch.bfloat16 else F32, P, HW, Cin, _p(w), _p(b), Cout, _i4(kinds), _f3(a), _f3(d), _p(out), _p(out_logits), _stream()), "ufm_head_tail")
+
+
+def dpt_tail_fused(x, B, h, w, Cin, w2, b2, Cmid, H, W, wt, bt, Ct, kinds, a, d, out, out_logits=None):
+    """upsample -> conv3x3 + ReLU -> conv1x1 -> adaptor in one kernel (split-bf16 input and 3x3 weights)."""
+    _t("ufm_dpt_tail_fused", 2.0 * B * H * W * Cmid * 9 * Cin)
+    _check(lib().ufm_dpt_tail_fused(_p(x), B, h, w, Cin, _p(w2), _p(b2), Cmid, H, W, _p(wt), _p(bt), Ct, _i4(kinds), _f3(a), _f3(d), _p(out), _p(out_logits), _stream()), "ufm_dpt_tail_fused")
 
 
 def unmap_flow(flow, B, h, w, rep0, src0, src1, H0, W0, out, valid=None):
