@@ -100,6 +100,14 @@ int ufm_debug_set_attn_variant(int v);
 /* Tuning hook for ufm_conv2d_nhwc_bf16x3: 0 = auto, 1 = 128-row kernels only, 2 = 256x256 8-phase kernel wherever applicable. */
 int ufm_debug_set_conv_variant(int v);
 
+/* `ufm infer` post-processing: warp the target image into the source frame with the predicted
+ * flow -- [R] utils/viz.py:11-59 warp_image_with_flow: F.grid_sample(bilinear, align_corners=False, zeros padding)
+ * at clip(x + flow_x, 0, Wt-1), clip(y + flow_y, 0, Ht-1).  target: HWC uint8 (tgt_dtype 0) or fp32 (1), 3 channels;
+ * flow: fp32 planar [2][H][W] (the layout of UFMFlowFieldOutput.flow_output[b]); out: fp32 [H][W][3].
+ * mask_mode 0: none; 1: out *= (mask > 0.5) (viz.py:56-57); 2: out = mask*out + (1-mask)*fill (cli.py:141-143). */
+int ufm_warp_bilinear(const void* target, int tgt_dtype, int Ht, int Wt, const float* flow, int H, int W,
+                      const float* mask, int mask_mode, float fill, float* out, void* stream);
+
 /* =====================================================================================
  * LayerNorm over the channel dim, eps inside the sqrt ([U] Block.norm1/norm2, encoder .norm,
  * info-sharing .norm; nn.LayerNorm(eps=1e-6)).  x: fp32 [*, D] rows of stride ldx.

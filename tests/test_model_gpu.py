@@ -261,3 +261,59 @@ def test_from_pretrained_roundtrip_on_device(env, tmp_path):
     assert again.inference_resolution == prod.inference_resolution
     src, tgt = u8((1, 56, 56, 3), 1).to(DEV), u8((1, 56, 56, 3), 2).to(DEV)
     assert torch.equal(prod.predict_correspondences_batched(src, tgt).flow.flow_output, again.predict_correspondences_batched(src, tgt).flow.flow_output)
+
+
+def test_warp_image_with_flow_matches_the_reference_goldens():
+    """ufm_amd.viz.warp_image_with_flow (HIP ufm_warp_bilinear) vs outputs of the reference's own
+    utils/viz.py:11-59 (tests/golden/make_viz_goldens.py), incl. flows far outside the target (clip) and the mask."""
+    import os
+
+    import numpy as np
+
+    from ufm_amd import viz
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "viz_warp.npz"))
+    for name in ("same", "differ"):
+        src, tgt, flow, mask = g[f"{name}_src"], g[f"{name}_tgt"], g[f"{name}_flow"], g[f"{name}_mask"]
+        got = viz.warp_image_with_flow(src, None, tgt, flow)
+        # the reference normalises the sampling grid to [-1, 1] in float32 and grid_sample un-normalises it: ~1e-5 px
+        # of coordinate noise on 0..255 data
+        assert np.abs(got - g[f"{name}_warped"]).max() <= 2e-2
+        got_m = viz.warp_image_with_flow(src, mask, tgt, flow)
+        assert np.abs(got_m - g[f"{name}_warped_masked"]).max() <= 2e-2
+
+
+def test_ufm_infer_cli_writes_the_reference_artefacts(tmp_path, monkeypatch):
+    """`ufm infer` (cli.py:85-156) end to end on a pair of real-sized synthetic PNGs with a tiny random-init model:
+    the three PNGs of the reference exist, have the source image's size, and the warped image equals the blend of
+    cli.py:141-143 recomputed from the model outputs."""
+    import numpy as np
+    from PIL import Image
+
+    import ufm_amd
+    from ufm_amd import cli, viz
+    from ufm_amd.modules import init_weights_
+
+    rng = np.random.default_rng(3)
+    src = rng.integers(0, 256, (90, 120, 3), dtype=np.uint8)
+    tgt = rng.integers(0, 256, (80, 110, 3), dtype=np.uint8)
+    Image.fromarray(src).save(tmp_path / "s.png")
+    Image.fromarray(tgt).save(tmp_path / "t.png")
+
+    def tiny(args):
+        m = ufm_amd.UniFlowMatchConfidence(**ufm_amd.ufm_tiny_config())
+        init_weights_(m, seed=0)
+        return m.eval().to(DEV).set_numerics(args.numerics)
+
+    monkeypatch.setattr(cli, "load_model", tiny)
+    out = tmp_path / "out"
+    cli.main(["infer", str(tmp_path / "s.png"), str(tmp_path / "t.png"), "-o", str(out)])
+    for name, channels in (("flow_visualization.png", 3), ("covisibility_mask.png", 1), ("warped_source.png", 3)):
+        a = np.asarray(Image.open(out / name))
+        assert a.shape[:2] == (90, 120) and (a.ndim == 3) == (channels == 3), (name, a.shape)
+    model = tiny(type("A", (), {"numerics": "fast"})())
+    res = model.predict_correspondences_batched(torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV))
+    flow, cov = res.flow.flow_output[0].cpu().numpy(), res.covisibility.mask[0].cpu().numpy()
+    want = cov[..., None] * viz.warp_image_with_flow(src, None, tgt, flow.transpose(1, 2, 0)) + (1 - cov[..., None]) * 255
+    got = np.asarray(Image.open(out / "warped_source.png")).astype(np.float32)
+    assert np.abs(got - np.clip(want, 0, 255).astype(np.uint8)).max() <= 1

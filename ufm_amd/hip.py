@@ -33,6 +33,7 @@ SIGNATURES = {
     "ufm_debug_set_gemm_variant": [_i],
     "ufm_debug_set_attn_variant": [_i],
     "ufm_debug_set_conv_variant": [_i],
+    "ufm_warp_bilinear": [_vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _f, _vp, _vp],
     "ufm_dpt_tail_fused": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "ufm_layernorm": [_vp, _i, _vp, _i, _i, _vp, _vp, _f, _vp, _i, _i, _vp],
     "ufm_fill_rows": [_vp, _i, _i, _i, _vp, _i, _vp],
@@ -228,6 +229,13 @@ def dpt_tail_fused(x, B, h, w, Cin, w2, b2, Cmid, H, W, wt, bt, Ct, kinds, a, d,
     """upsample -> conv3x3 + ReLU -> conv1x1 -> adaptor in one kernel (split-bf16 input and 3x3 weights)."""
     _t("ufm_dpt_tail_fused", 2.0 * B * H * W * Cmid * 9 * Cin)
     _check(lib().ufm_dpt_tail_fused(_p(x), B, h, w, Cin, _p(w2), _p(b2), Cmid, H, W, _p(wt), _p(bt), Ct, _i4(kinds), _f3(a), _f3(d), _p(out), _p(out_logits), _stream()), "ufm_dpt_tail_fused")
+
+
+def warp_bilinear(target, flow, out, mask=None, mask_mode=0, fill=0.0):
+    """target: (Ht, Wt, 3) uint8 or fp32; flow: (2, H, W) fp32; out: (H, W, 3) fp32; mask: (H, W) fp32 or None."""
+    Ht, Wt = target.shape[:2]
+    H, W = flow.shape[1:]
+    _check(lib().ufm_warp_bilinear(_p(target), 0 if target.dtype == torch.uint8 else 1, Ht, Wt, _p(flow), H, W, _p(mask), mask_mode, float(fill), _p(out), _stream()), "ufm_warp_bilinear")
 
 
 def unmap_flow(flow, B, h, w, rep0, src0, src1, H0, W0, out, valid=None):
