@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--gemm-variant", type=int, default=0, help="tuning hook: ufm_debug_set_gemm_variant (0 = auto)")
     ap.add_argument("--attn-variant", type=int, default=0, help="tuning hook: ufm_debug_set_attn_variant (0 = default)")
-    ap.add_argument("--serial-heads", action="store_true", help="run the two DPT heads on one stream")
+    ap.add_argument("--concurrent-heads", action="store_true", help="run the two DPT heads on separate streams (measured: no gain)")
     ap.add_argument("--micro-batches", type=int, default=2, help="concurrent micro-batches (HIP streams) per GPU; 1 = single stream")
     args = ap.parse_args()
 
@@ -75,7 +75,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # UFM_BENCH_FORCE_DIST=1: run the RCCL gather path with a single rank too (rehearsal of the N > 1 code on one GPU)
+    use_dist = world > 1 or os.environ.get("UFM_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist_
 
         dist = dist_
@@ -94,25 +96,25 @@ def main():
     init_weights_(model, seed=0)  # deterministic CPU RNG: identical weights on every rank
     model = model.to(dev).set_numerics(args.numerics)
     model.engine().micro_batches = args.micro_batches
-    model.engine().concurrent_heads = not args.serial_heads
+    model.engine().concurrent_heads = args.concurrent_heads
 
     B = args.batch
     g = torch.Generator().manual_seed(1234 + rank)  # each rank owns its own slice of the global batch
     src = torch.randint(0, 256, (B, res, res, 3), dtype=torch.uint8, generator=g).to(dev)
     tgt = torch.randint(0, 256, (B, res, res, 3), dtype=torch.uint8, generator=g).to(dev)
-    gathered = torch.empty((world * B, 3, res, res), device=dev) if world > 1 else None
-    packed = torch.empty((B, 3, res, res), device=dev) if world > 1 else None
+    gathered = torch.empty((world * B, 3, res, res), device=dev) if use_dist else None
+    packed = torch.empty((B, 3, res, res), device=dev) if use_dist else None
 
     def step():
         out = model.predict_correspondences_batched(src, tgt)
-        if world > 1:  # the trivial result gather: ONE collective per step on the packed buffer
+        if use_dist:  # the trivial result gather: ONE collective per step on the packed buffer
             packed[:, :2].copy_(out.flow.flow_output)
             packed[:, 2].copy_(out.covisibility.mask)
             dist.all_gather_into_tensor(gathered, packed)
         return out
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -127,7 +129,7 @@ def main():
         ev[i + 1].record()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -230,7 +232,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
