@@ -191,8 +191,8 @@ def main():
         if os.path.exists(pmc_path) and B == 8 and res == 518 and args.numerics == "fast":
             pmc = json.load(open(pmc_path))
         for k, v in kernels.items():
-            if k in pmc and "hbm_bytes_per_launch" in pmc[k]:
-                v["traffic"] = pmc[k]["hbm_bytes_per_launch"]
+            if k in pmc and "hbm_bytes_per_step" in pmc[k]:
+                v["traffic"] = pmc[k]["hbm_bytes_per_step"] / v["launches"]  # per C-ABI call, like `achieved`
                 v["mfma_busy_frac_pmc"] = pmc[k].get("mfma_busy_frac")
         line["roofline"] = {
             "kernel": dom, "bound": "mfma", "achieved": d["achieved"], "peak": d["peak"], "unit": "TFLOP/s", "frac": d["frac"],

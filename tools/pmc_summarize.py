@@ -5,8 +5,9 @@ coalesced reads -- MI355X_MICROARCH.md section HBM; WRITE_SIZE is exact for 16-B
 bank-conflict cycles."""
 import collections, csv, glob, json, sys
 out_path = sys.argv[1] if len(sys.argv) > 1 else "profiles/r01/pmc_step_summary.json"
+STEPS = 3  # tools/pmc_traffic.sh traces --warmup 1 --steps 2: three identical steps
 FAM = {"gemm_bf16": "ufm_gemm_bf16", "attn_bf16_kernel": "ufm_attention_bf16", "conv_x3": "ufm_conv2d_nhwc_bf16x3",
-       "layernorm_kernel": "ufm_layernorm", "upsample": "ufm_upsample_bilinear_nhwc", "head_tail": "ufm_head_tail",
+       "layernorm_kernel": "ufm_layernorm", "upsample": "ufm_upsample_bilinear_nhwc", "dpt_tail_fused": "ufm_dpt_tail_fused", "head_tail_kernel": "ufm_head_tail",
        "patchify": "ufm_patchify", "unmap": "ufm_unmap", "conv_f32": "ufm_conv2d_nhwc_f32"}
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in ("pmc_step_fetch", "pmc_step_write", "pmc_step_util"):
@@ -25,6 +26,10 @@ for fam, d in acc.items():
         e["hbm_write_bytes_per_launch"] = a["WRITE_SIZE"] * 1024
     if "FETCH_SIZE" in a and "WRITE_SIZE" in a:
         e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
+        # per step: one C-ABI call can be two kernel launches (hybrid 8-phase + 128-row split) -- bench.py divides this
+        # by ITS launch count (C-ABI calls) to get bytes per launch on the same basis as `achieved`
+        e["hbm_bytes_per_step"] = (sum(d["FETCH_SIZE"]) * 1024 * 2 + sum(d["WRITE_SIZE"]) * 1024) / STEPS
+        e["kernel_launches_per_step"] = len(d["FETCH_SIZE"]) / STEPS
     if "SQ_VALU_MFMA_BUSY_CYCLES" in a and a.get("GRBM_GUI_ACTIVE"):
         e["mfma_busy_frac"] = a["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * a["GRBM_GUI_ACTIVE"] / 8)
         e["wave_wait_frac"] = a["SQ_WAIT_ANY"] / a["SQ_WAVE_CYCLES"]
