@@ -471,11 +471,15 @@ def test_conv2d_bf16x3(hip, B, H, W, Cin, Cout, k, stride, pad, relu_in, act, nr
         (3, 23, 17, 64, 512, 1, 1, 0, False, 0, 1, 0),    # 1x1, nt = 2 (prologue only + tail waits)
         (2, 9, 11, 96, 1024, 1, 1, 0, False, 0, 0, 2),    # ConvTranspose (pixel-shuffle store), Co = 256
         (8, 148, 148, 32, 256, 3, 1, 1, True, 0, 1, 0),   # 685 tiles: auto = 2 whole rounds on the 8-phase kernel + 128-row rest
+        (2, 19, 19, 768, 256, 3, 1, 1, False, 0, 0, 0),   # 46 blocks of 64x64, 216 K-tiles: the deep ring incl. its drain
+        (1, 30, 30, 256, 64, 3, 1, 1, True, 0, 2, 0),     # 15 blocks of 64x64, 72 K-tiles, both residuals
+        (1, 9, 7, 32, 64, 1, 1, 0, False, 0, 0, 0),       # a single K-tile (nk = 1 < ring depth)
     ],
 )
 def test_conv2d_bf16x3_8phase_bit_identical(hip, B, H, W, Cin, Cout, k, stride, pad, relu_in, act, nres, shuffle):
-    """The 256x256 8-phase kernel does the same arithmetic in the same order as the 128-row kernels: outputs must be
-    BIT-identical (forced variant 2 = 8-phase everywhere, and variant 0 = the auto/hybrid split, vs variant 1)."""
+    """The 256x256 8-phase kernel and the deep-ring (NS = 4) small-grid kernels do the same arithmetic in the same order
+    as the plain 2-stage 128-row kernels: outputs must be BIT-identical (variant 3 = plain 2-stage only, 1 = 128-row
+    kernels incl. the deep ring, 2 = 8-phase everywhere, 0 = the auto/hybrid choice)."""
     lib = hip.lib()
     x = split(nhwc(rnd(B, Cin, H, W, seed=1))).to(DEV)
     w = split(rnd(Cout, k, k, Cin, seed=2, scale=(Cin * k * k) ** -0.5)).to(DEV)
@@ -486,7 +490,7 @@ def test_conv2d_bf16x3_8phase_bit_identical(hip, B, H, W, Cin, Cout, k, stride, 
     zero = torch.zeros(256, device=DEV)
     outs = {}
     try:
-        for variant in (1, 2, 0):
+        for variant in (3, 1, 2, 0):  # 3 = 128-row kernels with the plain 2-stage loop only: the baseline
             lib.ufm_debug_set_conv_variant(variant)
             out = torch.full(oshape, 7.0, device=DEV, dtype=torch.bfloat16)
             orl = None if shuffle else torch.full(oshape, 7.0, device=DEV, dtype=torch.bfloat16)
@@ -495,12 +499,12 @@ def test_conv2d_bf16x3_8phase_bit_identical(hip, B, H, W, Cin, Cout, k, stride, 
             outs[variant] = (out.cpu(), None if shuffle else orl.cpu())
     finally:
         lib.ufm_debug_set_conv_variant(0)
-    for v in (2, 0):
-        assert torch.equal(outs[1][0].view(torch.int16), outs[v][0].view(torch.int16))
+    for v in (1, 2, 0):
+        assert torch.equal(outs[3][0].view(torch.int16), outs[v][0].view(torch.int16))
         if not shuffle:
-            assert torch.equal(outs[1][1].view(torch.int16), outs[v][1].view(torch.int16))
+            assert torch.equal(outs[3][1].view(torch.int16), outs[v][1].view(torch.int16))
     if not shuffle:  # the second output is relu(out), exactly (what relu_in=1 would apply by the sign of hi)
-        assert torch.equal(unsplit(outs[1][1]), torch.relu(unsplit(outs[1][0])))
+        assert torch.equal(unsplit(outs[3][1]), torch.relu(unsplit(outs[3][0])))
 
 
 @pytest.mark.parametrize("s,Cin,Co", [(4, 32, 32), (2, 64, 48)])

@@ -22,8 +22,12 @@ constexpr int BK = 32;
 
 // BM x BN tile: 128x{128,64,32} for the big maps; 64x64 for the small grids (19^2 / 37^2: with 128-row tiles only 46-172
 // blocks exist, each a 72-216 step latency-bound K-loop -- 4x more, smaller blocks co-reside and overlap their DMA waits)
-template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvX3Args p) {
+// NS = LDS ring depth.  NS = 2: one vmcnt(0) + __syncthreads() per K-step, two co-resident blocks per CU hide each
+// other's DMA latency (big grids).  NS = 4 (BN >= 64): counted s_waitcnt vmcnt + raw s_barrier, two K-tiles stay in flight
+// across every barrier -- used for the 64x64 tile on small grids with long K loops (the 19^2 layers: 46-184 blocks, K up
+// to 6912), where nothing else on the CU covers the ~0.5 us of each K-step's DMA.  Same arithmetic order: results are bit-identical.
+template <int BM, int BN, int NS>
+__global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void conv_x3_kernel(ConvX3Args p) {
     constexpr int WN = BN >= 64 ? 2 : 1, WM = 4 / WN;
     constexpr int A_RPW = BM / 4, A_PIECES = A_RPW / 16;  // A rows / DMA pieces per wave and plane
     constexpr int TM = (BM / WM) / 16, TN = (BN / WN) / 16;
@@ -31,7 +35,9 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvX3Args p) {
     constexpr int STAGE_BYTES = 2 * (A_PLANE + W_PLANE);
     constexpr int W_ROWS_PER_WAVE = BN / 4;                             // 32 / 16 / 8
     constexpr int W_PIECES = W_ROWS_PER_WAVE >= 16 ? W_ROWS_PER_WAVE / 16 : 1;
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+    static_assert(NS == 2 || BN >= 64, "the deep ring needs the same DMA piece count in every wave");
+    constexpr int PIECES = 2 * (A_PIECES + W_PIECES);  // global_load_lds per wave and K-tile (BN >= 64)
+    __shared__ __attribute__((aligned(16))) char smem[NS * STAGE_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntn = p.Cout / BN;
@@ -116,12 +122,32 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvX3Args p) {
 #pragma unroll
         for (int m = 0; m < TM; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    stage(0, 0);
+    if (NS == 2) {
+        stage(0, 0);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NS - 1; ++i)
+            if (i < nk) stage(i, i);
+    }
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-        const char* s = smem + (kt & 1) * STAGE_BYTES;
+        if (NS == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        } else {
+            // K-tile kt has landed once at most the DMA pieces of the younger tiles (<= NS - 2 of them) are outstanding.
+            // RAW: every wave waits for its own pieces, then the barrier.  WAR: the slot restaged below was last read in
+            // iteration kt - 1, whose fragment reads every wave has retired (lgkmcnt(0) before its MFMAs) before this barrier.
+            const int younger = min(NS - 2, nk - 1 - kt);
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + NS - 1 < nk) stage((kt + NS - 1) % NS, kt + NS - 1);
+        }
+        const char* s = smem + (kt % NS) * STAGE_BYTES;
         bf16x8 ah[TM], al[TM], wh[TN], wl[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -156,7 +182,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvX3Args p) {
 }  // namespace
 
 static int g_conv_variant = 0;
-// test/tuning hook: 0 = auto, 1 = 128-row kernels only, 2 = 8-phase kernel wherever it is applicable
+// test/tuning hook: 0 = auto, 1 = 128-row kernels only, 2 = 8-phase kernel wherever it is applicable,
+// 3 = 128-row kernels only and never the deep (NS = 4) ring
 extern "C" int ufm_debug_set_conv_variant(int v) {
     g_conv_variant = v;
     return UFM_OK;
@@ -197,20 +224,26 @@ extern "C" int ufm_conv2d_nhwc_bf16x3(const uint16_t* in, int B, int H, int W, i
         // small grid: 64x64 tiles, several co-resident blocks per CU.  Threshold from an end-to-end sweep (400 / 200 / 100:
         // 189.6 / 196.6 / 197.2 pairs/s with two micro-batches): at 128..400 blocks the 128-row tiles win
         if (Cout % 64 == 0 && blocks128 < 128) {
-            hipLaunchKernelGGL((conv_x3_kernel<64, 64>), dim3((unsigned)(((Mq + 63) / 64) * (Cout / 64))), dim3(256), 0, (hipStream_t)stream, q);
+            const unsigned grid = (unsigned)(((Mq + 63) / 64) * (Cout / 64));
+            // measured per layer (tools/conv_breakdown.py): the deep ring pays on long K loops only (19^2 768->256: 138 -> 102 us;
+            // short loops lose 2-3 us to its prologue), and not at all on the 128x128 tile (37^2 RCU: 68 -> 83 us)
+            if (grid <= 512 && KH * KW * (Cin / 32) >= 64 && g_conv_variant != 3)
+                hipLaunchKernelGGL((conv_x3_kernel<64, 64, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, q);
+            else
+                hipLaunchKernelGGL((conv_x3_kernel<64, 64, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, q);
         } else if (Cout % 128 == 0) {
-            hipLaunchKernelGGL((conv_x3_kernel<128, 128>), dim3(ntm * (Cout / 128)), dim3(256), 0, (hipStream_t)stream, q);
+            hipLaunchKernelGGL((conv_x3_kernel<128, 128, 2>), dim3(ntm * (Cout / 128)), dim3(256), 0, (hipStream_t)stream, q);
         } else if (Cout % 64 == 0) {
-            hipLaunchKernelGGL((conv_x3_kernel<128, 64>), dim3(ntm * (Cout / 64)), dim3(256), 0, (hipStream_t)stream, q);
+            hipLaunchKernelGGL((conv_x3_kernel<128, 64, 2>), dim3(ntm * (Cout / 64)), dim3(256), 0, (hipStream_t)stream, q);
         } else {
-            hipLaunchKernelGGL((conv_x3_kernel<128, 32>), dim3(ntm * (Cout / 32)), dim3(256), 0, (hipStream_t)stream, q);
+            hipLaunchKernelGGL((conv_x3_kernel<128, 32, 2>), dim3(ntm * (Cout / 32)), dim3(256), 0, (hipStream_t)stream, q);
         }
     };
     const bool ok8 = Cout % 256 == 0 && KH * KW * (Cin / 32) >= 2 && p.in_plane < (1ll << 31) && p.w_plane < (1ll << 31);
     const long long t256 = ((M + 255) / 256) * (Cout / 256);
     if (ok8 && g_conv_variant == 2) {
         ufm_launch_conv_x3_8ph(p, (hipStream_t)stream);
-    } else if (ok8 && g_conv_variant == 0 && t256 >= 256) {
+    } else if (ok8 && g_conv_variant == 0 && t256 >= 256) {  // (variants 1 and 3 never take this branch)
         const long long full = t256 / 256;                          // whole rounds of the 8-phase kernel
         const long long m_main = full * 256 / (Cout / 256) * 256;   // leading pixels whose tiles fit in them
         if (m_main >= M || full == 0) {
