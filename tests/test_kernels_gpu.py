@@ -78,6 +78,34 @@ def test_gemm_bf16(hip, M, N, K, act, use_gamma, use_res, out_bf16, row_mod, row
     assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("M,N,K", [(256 * 9 + 77, 1024, 128), (256 * 7, 1024, 192), (5000, 2304, 768), (4 * 1370, 1024, 4096), (300, 256, 1024)])
+def test_gemm_8phase_bitwise_equals_128_kernel_repeated(hip, M, N, K):
+    """Race screen for the counted-vmcnt schedule: the 8-phase kernel (variant 4) and the hybrid split (5) accumulate in
+    the same K order as the 128x128 kernel (1), so all three must agree BIT FOR BIT -- over repeated launches (a DMA
+    that lands late shows up as a rare wrong tile), K-tile counts 2 (prologue + drain only), 3 (odd), 12, 64, ragged M."""
+    lib = hip.lib()
+    A = bf16r(rnd(M, K, seed=1)).to(DEV).bfloat16()
+    W = bf16r(rnd(N, K, seed=2, scale=K**-0.5)).to(DEV).bfloat16()
+    bias, res = rnd(N, seed=3, scale=0.1).to(DEV), rnd(M, N, seed=5).to(DEV)
+    try:
+        lib.ufm_debug_set_gemm_variant(1)
+        want = torch.zeros(M, N, device=DEV)
+        hip.gemm_bf16(A, W, M, N, K, want, bias=bias, res=res)
+        want_b = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+        hip.gemm_bf16(A, W, M, N, K, want_b, bias=bias, act=1)
+        for rep in range(6):
+            for variant in (4, 5):
+                lib.ufm_debug_set_gemm_variant(variant)
+                got = torch.full((M, N), 3.0, device=DEV)
+                hip.gemm_bf16(A, W, M, N, K, got, bias=bias, res=res)
+                assert torch.equal(got, want), (variant, rep)
+                got_b = torch.full((M, N), 3.0, device=DEV, dtype=torch.bfloat16)
+                hip.gemm_bf16(A, W, M, N, K, got_b, bias=bias, act=1)
+                assert torch.equal(got_b.view(torch.int16), want_b.view(torch.int16)), (variant, rep)
+    finally:
+        lib.ufm_debug_set_gemm_variant(0)
+
+
 @pytest.mark.parametrize("variant", [1, 4])
 def test_gemm_gelu_epilogue_accuracy(hip, variant):
     """The bf16-output GELU epilogue (gelu_bf16_x4: relu(x) - |x| 2^-g(|x|), one transcendental per value) against
