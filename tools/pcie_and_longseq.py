@@ -35,3 +35,18 @@ m = make(res)
 s = torch.randint(0, 256, (B, res, res, 3), dtype=torch.uint8, generator=g).cuda()
 t = torch.randint(0, 256, (B, res, res, 3), dtype=torch.uint8, generator=g).cuda()
 print("1036x1036, batch 2   : %.2f pairs/s  %.1f ms/step" % rate(lambda: m.predict_correspondences_batched(s, t), 5, B))
+del m; torch.cuda.empty_cache()
+# BASELINE config 4: UFM-Refine 518x518 (classification-refinement head on top of the same trunk)
+B, res = 8, 518
+m = ufm_amd.UniFlowMatchClassificationRefinement(**ufm_amd.ufm_refine_config(resolution_wh=(res, res))).eval()
+init_weights_(m, seed=0)
+m = m.to("cuda").set_numerics("fast")
+s = torch.randint(0, 256, (B, res, res, 3), dtype=torch.uint8, generator=g).cuda()
+t = torch.randint(0, 256, (B, res, res, 3), dtype=torch.uint8, generator=g).cuda()
+print("UFM-Refine 518, B=8  : %.1f pairs/s  %.2f ms/step" % rate(lambda: m.predict_correspondences_batched(s, t), 10, B))
+from ufm_amd import hip
+hip.TIMER = hip.KernelTimer()
+m.predict_correspondences_batched(s, t)
+for k, v in sorted(hip.TIMER.summary().items(), key=lambda kv: -kv[1]["ms"]):
+    print(f"   {k:30s} x{v['launches']:3d} {v['ms']:7.2f} ms")
+hip.TIMER = None

@@ -248,10 +248,12 @@ def unmap_channels(chan, B, Cc, h, w, rep0, src0, H0, W0, out, valid=None, chan_
 
 
 def refine(flow, feat, B, Cc, H, W, P, temperature, bias, residual, log_softmax=None):
+    _t("ufm_refine", 4.0 * B * H * W * (2 * Cc + 4 + (P * P if log_softmax is not None else 0)))  # both feature maps once, flow, residual, log-softmax
     _check(lib().ufm_refine(_p(flow), _p(feat), B, Cc, H, W, P, temperature, _p(bias), _p(residual), _p(log_softmax), _stream()), "ufm_refine")
 
 
 def pixel_shuffle_planar(x, B, gh, gw, Cc, p, out):
+    _t("ufm_pixel_shuffle_planar", 8.0 * B * gh * gw * p * p * Cc)
     _check(lib().ufm_pixel_shuffle_planar(_p(x), B, gh, gw, Cc, p, _p(out), _stream()), "ufm_pixel_shuffle_planar")
 
 
