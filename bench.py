@@ -188,8 +188,8 @@ def main():
         for name, d in summ.items():
             work = sum(m for m in d["metas"] if m)
             entry = {"launches": d["launches"], "ms_per_step": d["ms"], "avg_launch_us": 1e3 * d["ms"] / d["launches"]}
-            if name in ("ufm_gemm_bf16", "ufm_attention_bf16", "ufm_conv2d_nhwc_f32", "ufm_conv2d_nhwc_bf16x3", "ufm_attention_f32"):
-                peak = {"ufm_conv2d_nhwc_f32": PEAK_F32_TFLOPS, "ufm_attention_f32": PEAK_F32_TFLOPS, "ufm_conv2d_nhwc_bf16x3": PEAK_BF16X3_TFLOPS}.get(name, PEAK_BF16_TFLOPS)
+            if name in ("ufm_gemm_bf16", "ufm_attention_bf16", "ufm_conv2d_nhwc_f32", "ufm_conv2d_nhwc_bf16x3", "ufm_attention_f32", "ufm_dpt_tail_fused"):
+                peak = {"ufm_conv2d_nhwc_f32": PEAK_F32_TFLOPS, "ufm_attention_f32": PEAK_F32_TFLOPS, "ufm_conv2d_nhwc_bf16x3": PEAK_BF16X3_TFLOPS, "ufm_dpt_tail_fused": PEAK_BF16X3_TFLOPS}.get(name, PEAK_BF16_TFLOPS)
                 entry.update(bound="mfma", algorithmic_gflop=work / 1e9, achieved=work / (d["ms"] * 1e-3) / 1e12, peak=peak, unit="TFLOP/s")
                 entry["frac"] = entry["achieved"] / peak
             elif work:
