@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ufm_amd import hip
 lib = hip.lib()
 variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["1", "4"])]
-shapes = [(4096, 4096, 4096, "bf16"), (8192, 8192, 8192, "bf16"), (21904, 3072, 128, "bf16"), (21904, 3072, 256, "bf16"), (21904, 1024, 128, "res"),
+shapes = [(4096, 4096, 4096, "bf16"), (8192, 8192, 8192, "bf16"), (21904, 3072, 128, "bf16"), (21904, 3072, 128, "f32"), (21904, 3072, 256, "bf16"), (21904, 1024, 128, "res"), (21904, 1024, 128, "f32"),
           (21904, 3072, 1024, "bf16"), (21904, 1024, 1024, "res"), (21904, 4096, 1024, "gelu"), (21904, 1024, 4096, "res"),
           (10952, 3072, 1024, "bf16"), (10952, 1024, 1024, "res"), (10952, 4096, 1024, "gelu"), (10952, 1024, 4096, "res"),
           (21904, 2304, 768, "bf16"), (21904, 768, 768, "res"), (21904, 3072, 768, "gelu"), (21904, 768, 3072, "res")]
@@ -13,7 +13,7 @@ for M, N, K, mode in shapes:
     A = torch.randn(M, K, device="cuda").bfloat16()
     W = (torch.randn(N, K, device="cuda") * K**-0.5).bfloat16()
     bias = torch.randn(N, device="cuda") * 0.1
-    out = torch.randn(M, N, device="cuda") if mode == "res" else torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    out = torch.randn(M, N, device="cuda") if mode in ("res", "f32") else torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     def run():
         hip.gemm_bf16(A, W, M, N, K, out, bias=bias, act=hip.ACT_GELU if mode == "gelu" else hip.ACT_NONE, res=out if mode == "res" else None)
     times = {v: [] for v in variants}

@@ -95,47 +95,58 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& p, f32x4 (&acc)[4][
             *(f32x4*)(wave_lds + r * 256 + (((n * 4 + fq) ^ (r & 15)) << 4)) = v;
         }
     }
-    if (OUT_BF16 && !p.res && (p.ldo & 7) == 0 && ((uintptr_t)p.out & 15) == 0) {
-        // bf16 output without residual: a lane converts 8 consecutive columns (two staged chunks) and stores 16 B,
-        // a wave instruction covers 8 whole 128-B row segments (8-B-per-lane stores run at 0.54-0.70x the 16-B rate)
-        const int r8 = lane >> 3, c8 = lane & 7;
+    // Read-out.  PLAIN = the whole 64-row slice is inside M and no row re-mapping is in use (every tile but the ragged last
+    // row-panel of every GEMM but patch-embed): a straight-line, branch-free body, so the compiler issues all LDS reads
+    // and residual loads up front instead of one dependent {ds_read, wait, branch, convert, store} round trip per pass
+    // (that serialisation was ~12 us of fixed cost per 5-round GEMM: epilogue time = 11.9 us + bytes / 7.05 TB/s).
+    auto readout = [&](auto plain_c) {
+        constexpr bool PLAIN = decltype(plain_c)::value;
+        if (OUT_BF16 && !p.res && (p.ldo & 7) == 0 && ((uintptr_t)p.out & 15) == 0) {
+            // bf16 output without residual: a lane converts 8 consecutive columns (two staged chunks) and stores 16 B,
+            // a wave instruction covers 8 whole 128-B row segments
+            const int r8 = lane >> 3, c8 = lane & 7;
 #pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
-            const int r = pass * 8 + r8;
-            const f32x4 v0 = *(const f32x4*)(wave_lds + r * 256 + (((2 * c8) ^ (r & 15)) << 4));
-            const f32x4 v1 = *(const f32x4*)(wave_lds + r * 256 + (((2 * c8 + 1) ^ (r & 15)) << 4));
-            const int row = row0 + r;
-            if (row >= p.M) continue;
-            const int orow = (p.out_row_group > 0)
-                                 ? (row / p.out_row_group) * (p.out_row_group + 1) + 1 + row % p.out_row_group
-                                 : row;
-            u32x4 pk = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
-            *(u32x4*)((uint16_t*)p.out + (size_t)orow * p.ldo + col0 + c8 * 8) = pk;
+            for (int pass = 0; pass < 8; ++pass) {
+                const int r = pass * 8 + r8;
+                const f32x4 v0 = *(const f32x4*)(wave_lds + r * 256 + (((2 * c8) ^ (r & 15)) << 4));
+                const f32x4 v1 = *(const f32x4*)(wave_lds + r * 256 + (((2 * c8 + 1) ^ (r & 15)) << 4));
+                const int row = row0 + r;
+                int orow = row;
+                if (!PLAIN) {
+                    if (row >= p.M) continue;
+                    if (p.out_row_group > 0) orow = (row / p.out_row_group) * (p.out_row_group + 1) + 1 + row % p.out_row_group;
+                }
+                u32x4 pk = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
+                *(u32x4*)((uint16_t*)p.out + (size_t)orow * p.ldo + col0 + c8 * 8) = pk;
+            }
+            return;
         }
-        return;
-    }
-    const int rr = lane >> 4, c = lane & 15;
-#pragma unroll
-    for (int pass = 0; pass < 16; ++pass) {
-        const int r = pass * 4 + rr;
-        f32x4 v = *(const f32x4*)(wave_lds + r * 256 + ((c ^ (r & 15)) << 4));
-        const int row = row0 + r;
-        if (row >= p.M) continue;
+        const int rr = lane >> 4, c = lane & 15;
         const int nb = col0 + c * 4;
-        if (p.res) {
-            const int rrow = (p.res_row_mod > 0) ? (row % p.res_row_mod) : row;
-            v += *(const f32x4*)(p.res + (size_t)rrow * p.ldres + nb);
+#pragma unroll
+        for (int pass = 0; pass < 16; ++pass) {
+            const int r = pass * 4 + rr;
+            f32x4 v = *(const f32x4*)(wave_lds + r * 256 + ((c ^ (r & 15)) << 4));
+            const int row = row0 + r;
+            int rrow = row, orow = row;
+            if (!PLAIN) {
+                if (row >= p.M) continue;
+                if (p.res_row_mod > 0) rrow = row % p.res_row_mod;
+                if (p.out_row_group > 0) orow = (row / p.out_row_group) * (p.out_row_group + 1) + 1 + row % p.out_row_group;
+            }
+            if (p.res) v += *(const f32x4*)(p.res + (size_t)rrow * p.ldres + nb);
+            if (OUT_BF16) {
+                u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                *(u32x2*)((uint16_t*)p.out + (size_t)orow * p.ldo + nb) = pk;
+            } else {
+                *(f32x4*)((float*)p.out + (size_t)orow * p.ldo + nb) = v;
+            }
         }
-        const int orow = (p.out_row_group > 0)
-                             ? (row / p.out_row_group) * (p.out_row_group + 1) + 1 + row % p.out_row_group
-                             : row;
-        if (OUT_BF16) {
-            u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-            *(u32x2*)((uint16_t*)p.out + (size_t)orow * p.ldo + nb) = pk;
-        } else {
-            *(f32x4*)((float*)p.out + (size_t)orow * p.ldo + nb) = v;
-        }
-    }
+    };
+    if (row0 + 64 <= p.M && p.res_row_mod == 0 && p.out_row_group == 0)
+        readout(std::integral_constant<bool, true>{});
+    else
+        readout(std::integral_constant<bool, false>{});
 }
 
 
