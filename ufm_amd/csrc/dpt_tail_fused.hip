@@ -11,7 +11,8 @@
 // 32 output channels.  The 128 input channels are processed in four passes of 32 (77.5 KiB of LDS: two blocks per
 // CU, so one block's fill (VALU + loads) overlaps the other's MFMA pass):
 //   fill : the 18 x 18 halo tile of the UPSAMPLED map is computed straight from the h x w source (same fp32
-//          expression as upsample_split8_kernel), split into (hi, lo) bf16 and parked in LDS: [324 px][hi 64 B | lo 64 B],
+//          operations in the same order as upsample_split8_kernel, evaluated separably: horizontal lerps of the
+//          <= 13 source rows first), split into (hi, lo) bf16 and parked in LDS: [324 px][hi 64 B | lo 64 B],
 //          16-byte chunk index XOR (px & 7) (conflict-free ds_read_b128 for 16 consecutive pixels); zero outside the
 //          image (= the convolution's padding);
 //   mma  : K order = 32-channel chunk outer, filter tap inner (conv_bf16x3.hip's order); the A fragment of a tap is
@@ -29,6 +30,7 @@ constexpr int CIN = 128, CMID = 32, CQ = 32;         // channels per pass (= one
 constexpr int HALO_B = NPX * 128;                    // per pixel 128 B: [hi: 32 ch | lo: 32 ch] -> 41,472 B
 constexpr int WQ_B = 9 * 2 * CMID * 64;              // the 3x3 weights of one 32-channel pass: [tap][plane][32 cout][64 B] = 36 KiB
 constexpr int SMEM_B = HALO_B + WQ_B;                // 77.5 KiB: two blocks per CU
+constexpr int TROWS = 13;                            // source rows of the separable fill: T[13][18][32] fp32 = 29,952 B <= WQ_B
 
 __device__ __forceinline__ int swz64(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }  // 64-B rows (conv_bf16x3.hip)
 
@@ -84,35 +86,65 @@ __global__ __launch_bounds__(256, 2) void dpt_tail_fused_kernel(TailFusedArgs p)
 #pragma unroll
     for (int j = 0; j < 2; ++j) w_off[j] = HALO_B + (j * 16 + fr) * 64 + ((fq ^ swz64(j * 16 + fr)) << 4);
 
+    // source rows this tile's 18 halo rows interpolate between (host guarantees <= TROWS of them)
+    const int ybase = (int)(p.sy * max(ty0 - 1, 0));
+    const int ytop = min(p.h - 1, (int)(p.sy * min(ty0 + TS, p.H - 1)) + 1);
+    const int nrows = ytop - ybase + 1;
     for (int q = 0; q < CIN / CQ; ++q) {
         if (q) __syncthreads();  // every wave is done reading the previous pass's tile and weights
         u32x4 wreg[9];           // this pass's weights: loaded now, parked in LDS after the fill (latency under the fill)
 #pragma unroll
         for (int it = 0; it < 9; ++it) wreg[it] = *(const u32x4*)(w_src + it * CIN + q * CQ);
-        // ---- fill: upsampled halo tile of channels [32 q, 32 q + 32) ----
+        // ---- fill, separable.  Stage A: T[r][hx] = lx0 * v[y][x0] + lx1 * v[y][x1] for the <= 13 source rows y the tile
+        // touches and its 18 halo columns (fp32, parked in the weight region, which is idle until the fill is done).
+        // Stage B: halo[hy][hx] = split(ly0 * T[r0][hx] + ly1 * T[r1][hx]).  Same operations in the same order as the
+        // one-step form ly0 * (lx0 v00 + lx1 v01) + ly1 * (lx0 v10 + lx1 v11), so the result is bit-identical, with
+        // 2.8x fewer global loads and ~1/3 less VALU work (each horizontal lerp is shared by ~1.75 output rows). ----
+        float* T = (float*)(smem + HALO_B);
+        for (int u = tid; u < nrows * (HS * 4); u += 256) {
+            const int r = u / (HS * 4), rem = u - r * (HS * 4);
+            const int hx = rem >> 2, c8 = rem & 3;
+            const int ox = tx0 - 1 + hx;
+            if ((unsigned)ox >= (unsigned)p.W) continue;  // never read
+            const float fx = p.sx * ox;
+            const int x0 = (int)fx;
+            const int x1 = x0 + (x0 < p.w - 1 ? 1 : 0);
+            const float lx1 = fx - x0, lx0 = 1.f - lx1;
+            const uint16_t* src = p.in + ((size_t)b * p.h + (ybase + r)) * p.w * CIN + q * CQ + c8 * 8;
+            float v0[8], v1[8];
+            ld_split8(src + (size_t)x0 * CIN, p.in_plane, v0);
+            ld_split8(src + (size_t)x1 * CIN, p.in_plane, v1);
+            f32x4 t0, t1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                t0[k] = lx0 * v0[k] + lx1 * v1[k];
+                t1[k] = lx0 * v0[4 + k] + lx1 * v1[4 + k];
+            }
+            float* dst = T + (r * HS + hx) * 32 + c8 * 8;
+            *(f32x4*)dst = t0;
+            *(f32x4*)(dst + 4) = t1;
+        }
+        __syncthreads();
         for (int u = tid; u < NPX * 4; u += 256) {
             const int px = u >> 2, c8 = u & 3;
             const int hy = px / HS, hx = px - hy * HS;
             const int oy = ty0 - 1 + hy, ox = tx0 - 1 + hx;
             u32x4 ph = {0u, 0u, 0u, 0u}, pl = {0u, 0u, 0u, 0u};
             if ((unsigned)oy < (unsigned)p.H && (unsigned)ox < (unsigned)p.W) {
-                const float fy = p.sy * oy, fx = p.sx * ox;
-                const int y0 = (int)fy, x0 = (int)fx;
-                const int y1 = y0 + (y0 < p.h - 1 ? 1 : 0), x1 = x0 + (x0 < p.w - 1 ? 1 : 0);
-                const float ly1 = fy - y0, lx1 = fx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-                const uint16_t* src = p.in + (size_t)b * p.h * p.w * CIN + q * CQ + c8 * 8;
-                float v00[8], v01[8], v10[8], v11[8];
-                ld_split8(src + ((size_t)y0 * p.w + x0) * CIN, p.in_plane, v00);
-                ld_split8(src + ((size_t)y0 * p.w + x1) * CIN, p.in_plane, v01);
-                ld_split8(src + ((size_t)y1 * p.w + x0) * CIN, p.in_plane, v10);
-                ld_split8(src + ((size_t)y1 * p.w + x1) * CIN, p.in_plane, v11);
+                const float fy = p.sy * oy;
+                const int y0 = (int)fy;
+                const int y1 = y0 + (y0 < p.h - 1 ? 1 : 0);
+                const float ly1 = fy - y0, ly0 = 1.f - ly1;
+                const float* a = T + ((y0 - ybase) * HS + hx) * 32 + c8 * 8;
+                const float* c = T + ((y1 - ybase) * HS + hx) * 32 + c8 * 8;
+                const f32x4 a0 = *(const f32x4*)a, a1 = *(const f32x4*)(a + 4), c0 = *(const f32x4*)c, c1 = *(const f32x4*)(c + 4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float r[2], hh[2];
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         const int k = 2 * j + e;
-                        r[e] = ly0 * (lx0 * v00[k] + lx1 * v01[k]) + ly1 * (lx0 * v10[k] + lx1 * v11[k]);
+                        r[e] = ly0 * (k < 4 ? a0[k & 3] : a1[k & 3]) + ly1 * (k < 4 ? c0[k & 3] : c1[k & 3]);
                         hh[e] = bf16_to_f32(f32_to_bf16(r[e]));
                     }
                     ph[j] = pack_bf16x2(hh[0], hh[1]);
@@ -123,6 +155,7 @@ __global__ __launch_bounds__(256, 2) void dpt_tail_fused_kernel(TailFusedArgs p)
             *(u32x4*)(dst + ((c8 ^ (px & 7)) << 4)) = ph;
             *(u32x4*)(dst + (((4 + c8) ^ (px & 7)) << 4)) = pl;
         }
+        __syncthreads();  // T (in the weight region) has been consumed
 #pragma unroll
         for (int it = 0; it < 9; ++it) *(u32x4*)(w_dst + it * 4096) = wreg[it];
         __syncthreads();
@@ -217,6 +250,8 @@ extern "C" int ufm_dpt_tail_fused(const uint16_t* in, int B, int h, int w, int C
     UFM_REQUIRE(in && w2 && b2 && wt && bt && out && kind_host && a_host && d_host, "ufm_dpt_tail_fused: null pointer");
     UFM_REQUIRE(Cin == CIN && Cmid == CMID, "ufm_dpt_tail_fused: built for 128 -> 32 channels, got %d -> %d", Cin, Cmid);
     UFM_REQUIRE(B > 0 && h > 1 && w > 1 && H > 1 && W > 1 && Ct >= 1 && Ct <= 4, "ufm_dpt_tail_fused: bad shape");
+    UFM_REQUIRE((double)(h - 1) / (H - 1) * (TS + 1) + 2.0 <= TROWS && h <= H && w <= W,
+                "ufm_dpt_tail_fused: built for up-sampling ratios (h-1)/(H-1) <= 0.64 (got %d -> %d)", h, H);
     UFM_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)w2 % 16) == 0 && ((uintptr_t)wt % 16) == 0 && ((uintptr_t)b2 % 16) == 0,
                 "ufm_dpt_tail_fused: misaligned pointer");
     TailFusedArgs p{};

@@ -377,7 +377,8 @@ class Engine:
         out = torch.empty((B, hw.tail_cout, H, W), device=self.dev, dtype=torch.float32)
         logits = torch.empty_like(out) if 1 in hw.kinds else None
         c2a = hw.p_conv2a
-        if self.fused_tail and self.head_split and (c2a.cin, c2a.cout, c2a.k, c2a.stride, c2a.pad, hw.tail_cin) == (128, 32, 3, 1, 1, 32):
+        up_ok = h8 <= H and w8 <= W and max((h8 - 1) / (H - 1), (w8 - 1) / (W - 1)) * 17 + 2 <= 13  # the kernel's halo-row budget
+        if self.fused_tail and self.head_split and up_ok and (c2a.cin, c2a.cout, c2a.k, c2a.stride, c2a.pad, hw.tail_cin) == (128, 32, 3, 1, 1, 32):
             # upsample -> conv3x3 + ReLU -> conv1x1 -> adaptor in one kernel: the two full-resolution maps stay on chip
             hip.dpt_tail_fused(c1, B, h8, w8, 128, c2a.w, c2a.b, 32, H, W, hw.tail_w, hw.tail_b, hw.tail_cout, hw.kinds, hw.scale, hw.shift, out, logits)
         else:
