@@ -317,3 +317,26 @@ def test_ufm_infer_cli_writes_the_reference_artefacts(tmp_path, monkeypatch):
     want = cov[..., None] * viz.warp_image_with_flow(src, None, tgt, flow.transpose(1, 2, 0)) + (1 - cov[..., None]) * 255
     got = np.asarray(Image.open(out / "warped_source.png")).astype(np.float32)
     assert np.abs(got - np.clip(want, 0, 255).astype(np.uint8)).max() <= 1
+
+
+def test_full_size_batch_shards_are_bitwise_equal_across_kernel_dispatch(env):
+    """UFM-Base at 518^2, numerics "fast": a batch of 5 pairs (two concurrent micro-batches of 3 and 2: 8-phase GEMM /
+    conv + hybrid splits at those M) must equal the same pairs run one at a time (other tile shapes, other kernels) BIT
+    FOR BIT -- every kernel variant accumulates in the same order, and pairs are independent.  This is the
+    multi-GPU batch split at the benchmark's real shapes, and an end-to-end race screen of the
+    counted-vmcnt kernels."""
+    ufm_amd, _ = env
+    from ufm_amd.modules import init_weights_
+
+    model = ufm_amd.UniFlowMatchConfidence(**ufm_amd.ufm_base_config()).eval()
+    init_weights_(model, seed=0)
+    model = model.to(DEV).set_numerics("fast")
+    src, tgt = u8((5, 518, 518, 3), 11).to(DEV), u8((5, 518, 518, 3), 12).to(DEV)
+    whole = model.predict_correspondences_batched(src, tgt)
+    wf, wm = whole.flow.flow_output.clone(), whole.covisibility.mask.clone()
+    for i in range(5):
+        one = model.predict_correspondences_batched(src[i : i + 1], tgt[i : i + 1])
+        assert torch.equal(one.flow.flow_output[0], wf[i]), i
+        assert torch.equal(one.covisibility.mask[0], wm[i]), i
+    again = model.predict_correspondences_batched(src, tgt)
+    assert torch.equal(again.flow.flow_output, wf) and torch.equal(again.covisibility.mask, wm)
