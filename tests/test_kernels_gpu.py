@@ -500,6 +500,8 @@ def test_conv2d_bf16x3(hip, B, H, W, Cin, Cout, k, stride, pad, relu_in, act, nr
         (2, 9, 11, 96, 1024, 1, 1, 0, False, 0, 0, 2),    # ConvTranspose (pixel-shuffle store), Co = 256
         (8, 148, 148, 32, 256, 3, 1, 1, True, 0, 1, 0),   # 685 tiles: auto = 2 whole rounds on the 8-phase kernel + 128-row rest
         (2, 19, 19, 768, 256, 3, 1, 1, False, 0, 0, 0),   # 46 blocks of 64x64, 216 K-tiles: the deep ring incl. its drain
+        (3, 41, 37, 64, 128, 3, 1, 1, True, 0, 1, 0),     # Cout = 128: the 512 px x 128 cout 8-phase layout (ragged M = 4551)
+        (2, 30, 30, 96, 384, 3, 2, 1, False, 2, 0, 0),    # Cout = 384 = 3 x 128: three column tiles of the 512 x 128 layout, stride 2
         (1, 30, 30, 256, 64, 3, 1, 1, True, 0, 2, 0),     # 15 blocks of 64x64, 72 K-tiles, both residuals
         (1, 9, 7, 32, 64, 1, 1, 0, False, 0, 0, 0),       # a single K-tile (nk = 1 < ring depth)
     ],

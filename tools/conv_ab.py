@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ufm_amd import hip
 lib = hip.lib()
 B = 8
-shapes = [(148, 256, 256, 3, True, 1), (74, 256, 256, 3, True, 1), (37, 256, 256, 3, True, 1), (296, 256, 256, 3, False, 0),
+shapes = [(296, 256, 128, 3, False, 0), (148, 256, 256, 3, True, 1), (74, 256, 256, 3, True, 1), (37, 256, 256, 3, True, 1), (296, 256, 256, 3, False, 0),
           (148, 192, 256, 3, False, 0), (74, 384, 256, 3, False, 0), (148, 96, 256, 1, False, 0)]
 for h, cin, cout, k, relu, nres in shapes:
     x = torch.randn(2, B, h, h, cin, device="cuda").bfloat16()

@@ -1,4 +1,4 @@
-// 256 px x 256 cout x 32 ch "8-phase" bf16x3 implicit-GEMM convolution: the schedule of gemm_bf16_8ph.hip (ping-pong
+// 256 px x 256 cout (or 512 px x 128 cout) x 32 ch "8-phase" bf16x3 implicit-GEMM convolution: the schedule of gemm_bf16_8ph.hip (ping-pong
 // wave groups, counted vmcnt, four half-tiles in flight, no vmcnt(0)/__syncthreads in the loop) applied to the
 // split-precision convolution of conv_bf16x3.hip.  Same arithmetic in the same order (K-tile = 32 channels of one
 // filter tap, channel-chunk major / tap inner; per K-tile wl*ah, wh*al, wh*ah), so its results are BIT-IDENTICAL
@@ -15,8 +15,10 @@
 
 namespace {
 
-constexpr int HALF = 2 * 128 * 64;  // 16 KiB half-tile: [plane][128 rows][64 B]
-constexpr int PLANE = 128 * 64;
+// Wave layouts (WR x WC waves, 128 px x 64 cout per wave in both):
+//   2 x 4 : 256 px x 256 cout  -- half-tiles X 128 rows (16 KiB), W 128 rows (16 KiB); 128 KiB of LDS
+//   4 x 2 : 512 px x 128 cout  -- half-tiles X 256 rows (32 KiB), W  64 rows ( 8 KiB); 160 KiB of LDS (all of it)
+// A half-tile is [plane (hi, lo)][rows][64 B]; a DMA piece is 16 rows of one plane (1 KiB).
 
 template <int K>
 using IC = std::integral_constant<int, K>;
@@ -30,55 +32,84 @@ struct TapIter {  // walks the K-tiles of one half-tile kind: channel-chunk oute
     int tap, kh, kw, c0;
 };
 
+template <int WR, int WC>
 __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
-    __shared__ __attribute__((aligned(16))) char smem[8 * HALF];  // [tile & 1][kind]
+    static_assert(WR * WC == 8, "eight waves");
+    constexpr int XROWS = WR * 64, WROWS = WC * 32;           // rows of an X / W half-tile
+    constexpr int XPLANE = XROWS * 64, WPLANE = WROWS * 64;   // bytes of one plane
+    constexpr int XHALF = 2 * XPLANE, WHALF = 2 * WPLANE;
+    constexpr int KTILE = 2 * (XHALF + WHALF);                // one K-tile buffer: [W-lo][X-lo][W-hi][X-hi]
+    constexpr int XP = XROWS / 16 * 2 / 8, WP = WROWS / 16 * 2 / 8;  // DMA pieces per wave and half-tile: 2|4 and 2|1
+    constexpr int INFLIGHT = 2 * (XP + WP);                   // pieces of the four half-tiles kept in flight
+    __shared__ __attribute__((aligned(16))) char smem[2 * KTILE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
+    const int wr = wave / WC, wc = wave % WC;
+    auto half_off = [](int kind) { return kind == 0 ? 0 : kind == 1 ? WHALF : kind == 2 ? WHALF + XHALF : 2 * WHALF + XHALF; };
 
-    const int ntn = p.Cout >> 8;
+    const int ntn = p.Cout / (WC * 64);
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tmi = bid / ntn, tni = bid - tmi * ntn;
-    const int m0 = p.m_begin + (tmi << 8), n0 = tni << 8;
+    const int m0 = p.m_begin + tmi * (WR * 128), n0 = tni * (WC * 64);
     const int ntaps = p.KH * p.KW;
     const int nt = ntaps * (p.Cin >> 5);
     const unsigned ktot = (unsigned)(ntaps * p.Cin);
 
-    // ---- DMA sources.  Wave w stages rows [16w, 16w+16) of every half-tile, hi and lo plane ----
+    // ---- DMA sources.  X half-tile: wave w stages row-pieces w (and 8 + w when there are 16), hi and lo plane.
+    // W half-tile: 8 row-pieces -> wave w stages piece w, both planes; 4 row-pieces -> piece w & 3 of plane w >> 2 ----
     const int srow = lane >> 2, slot = lane & 3;
-    const int lr = wave * 16 + srow;
-    const unsigned chunk = (unsigned)((slot ^ swz(lr)) * 8);
-    int x_iy0[2], x_ix0[2];
-    unsigned x_img[2], w_src[2];
+    constexpr int XPR = XP / 2;  // X row-pieces per wave
+    int x_iy0[2][XPR], x_ix0[2][XPR];
+    unsigned x_img[2][XPR], x_chunk[XPR], w_src[2];
+#pragma unroll
+    for (int i = 0; i < XPR; ++i) {
+        const int lr = (i * 8 + wave) * 16 + srow;
+        x_chunk[i] = (unsigned)((slot ^ swz(lr)) * 8);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int brow = (lr >> 6) * 128 + h * 64 + (lr & 63);  // X half h: pixel rows mh = h of every wave row
+            const int m = min(m0 + brow, p.M - 1);
+            const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
+            x_iy0[h][i] = oy * p.stride - p.pad;
+            x_ix0[h][i] = ox * p.stride - p.pad;
+            x_img[h][i] = (unsigned)b * (unsigned)(p.H * p.W);
+        }
+    }
+    const int w_piece = WP == 2 ? wave : (wave & 3), w_plane_sel = WP == 2 ? 0 : (wave >> 2);
+    const int wlr = w_piece * 16 + srow;
+    const unsigned w_chunk = (unsigned)((slot ^ swz(wlr)) * 8);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const int brow = (lr >> 6) * 128 + h * 64 + (lr & 63);  // X half h: pixel rows mh = h of both wave groups
-        const int m = min(m0 + brow, p.M - 1);
-        const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
-        x_iy0[h] = oy * p.stride - p.pad;
-        x_ix0[h] = ox * p.stride - p.pad;
-        x_img[h] = (unsigned)b * (unsigned)(p.H * p.W);
-        const int bcol = (lr >> 5) * 64 + h * 32 + (lr & 31);   // W half h: couts nh = h of the four wave columns
-        w_src[h] = (unsigned)(n0 + bcol) * ktot + chunk;
+        const int bcol = (wlr >> 5) * 64 + h * 32 + (wlr & 31);     // W half h: couts nh = h of every wave column
+        w_src[h] = (unsigned)(n0 + bcol) * ktot + w_chunk;
     }
     TapIter it[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     auto stage = [&](auto kind, int tile) {  // kind: 0 W-lo, 1 X-lo, 2 W-hi, 3 X-hi ; issues this kind's NEXT K-tile
         constexpr int KIND = decltype(kind)::value;
         constexpr int H = KIND >> 1;
         TapIter& ti = it[KIND];
-        char* dst = smem + ((tile & 1) * 4 + KIND) * HALF + wave * 1024;
-        const uint16_t *src, *src_lo;
+        char* base = smem + (tile & 1) * KTILE + half_off(KIND);
         if (KIND & 1) {
-            const int iy = x_iy0[H] + ti.kh, ix = x_ix0[H] + ti.kw;
-            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            src = ok ? p.in + ((x_img[H] + (unsigned)(iy * p.W + ix)) * (unsigned)p.Cin + (unsigned)ti.c0 + chunk) : p.zero + chunk;
-            src_lo = ok ? src + p.in_plane : src;
+#pragma unroll
+            for (int i = 0; i < XPR; ++i) {
+                const int iy = x_iy0[H][i] + ti.kh, ix = x_ix0[H][i] + ti.kw;
+                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const uint16_t* src = ok ? p.in + ((x_img[H][i] + (unsigned)(iy * p.W + ix)) * (unsigned)p.Cin + (unsigned)ti.c0 + x_chunk[i]) : p.zero + x_chunk[i];
+                const uint16_t* src_lo = ok ? src + p.in_plane : src;
+                char* dst = base + (i * 8 + wave) * 1024;
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(dst), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src_lo), LDS_PTR(dst + XPLANE), 16, 0, 0);
+            }
         } else {
-            src = p.w + (w_src[H] + (unsigned)(ti.tap * p.Cin + ti.c0));
-            src_lo = src + p.w_plane;
+            const uint16_t* src = p.w + (w_src[H] + (unsigned)(ti.tap * p.Cin + ti.c0));
+            char* dst = base + w_piece * 1024;
+            if (WP == 2) {
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(dst), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + p.w_plane), LDS_PTR(dst + WPLANE), 16, 0, 0);
+            } else {
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + (w_plane_sel ? p.w_plane : 0)), LDS_PTR(dst + w_plane_sel * WPLANE), 16, 0, 0);
+            }
         }
-        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(dst), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src_lo), LDS_PTR(dst + PLANE), 16, 0, 0);
         if (++ti.kw == p.KW) ti.kw = 0, ++ti.kh;
         if (++ti.tap == ntaps) ti.tap = 0, ti.kh = 0, ti.kw = 0, ti.c0 += 32;
     };
@@ -107,19 +138,19 @@ __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
     bf16x8 xf[4][2], wa[2][2], wb[2][2];  // [frag][plane]
 
     auto read_x = [&](int tile, int mh) {
-        const char* s = smem + ((tile & 1) * 4 + 1 + 2 * mh) * HALF;
+        const char* s = smem + (tile & 1) * KTILE + half_off(1 + 2 * mh);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             xf[i][0] = *(const bf16x8*)(s + x_off[i]);
-            xf[i][1] = *(const bf16x8*)(s + PLANE + x_off[i]);
+            xf[i][1] = *(const bf16x8*)(s + XPLANE + x_off[i]);
         }
     };
     auto read_w = [&](bf16x8 (&w)[2][2], int tile, int nh) {
-        const char* s = smem + ((tile & 1) * 4 + 2 * nh) * HALF;
+        const char* s = smem + (tile & 1) * KTILE + half_off(2 * nh);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             w[j][0] = *(const bf16x8*)(s + w_off[j]);
-            w[j][1] = *(const bf16x8*)(s + PLANE + w_off[j]);
+            w[j][1] = *(const bf16x8*)(s + WPLANE + w_off[j]);
         }
     };
     auto mma = [&](auto mh_, auto nh_, bf16x8 (&w)[2][2], bool fresh_x) {
@@ -156,12 +187,12 @@ __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
         const int ph = 4 * tile + I;
         if (ph + 6 < nhalf) {
             stage(IC<(I + 2) & 3>{}, tile + (I + 6) / 4);
-            wait_vmcnt<8>();
+            wait_vmcnt<INFLIGHT>();  // the four youngest half-tiles are always two X and two W
         } else {
-            const int inflight = nhalf - ph - 3;  // half-tiles issued after half-tile ph + 2
-            if (inflight >= 3) wait_vmcnt<6>();
-            else if (inflight == 2) wait_vmcnt<4>();
-            else if (inflight == 1) wait_vmcnt<2>();
+            const int inflight = nhalf - ph - 3;  // half-tiles issued after half-tile ph + 2: the LAST ones of the stream
+            if (inflight >= 3) wait_vmcnt<2 * XP + WP>();   // X-lo, W-hi, X-hi
+            else if (inflight == 2) wait_vmcnt<XP + WP>();  // W-hi, X-hi
+            else if (inflight == 1) wait_vmcnt<XP>();       // X-hi
             else wait_vmcnt<0>();
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -190,7 +221,7 @@ __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
     stage(IC<3>{}, 0);
     stage(IC<0>{}, 1);
     stage(IC<1>{}, 1);
-    wait_vmcnt<8>();
+    wait_vmcnt<INFLIGHT>();  // half-tiles 0 (W-lo) and 1 (X-lo) of tile 0 have landed: W-hi, X-hi, W-lo, X-lo may be in flight
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -217,7 +248,12 @@ __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
 }  // namespace
 
 int ufm_launch_conv_x3_8ph(const ConvX3Args& p, hipStream_t stream) {
-    const int ntm = (p.M - p.m_begin + 255) / 256;
-    hipLaunchKernelGGL(conv_x3_8ph_kernel, dim3(ntm * (p.Cout / 256)), dim3(512), 0, stream, p);
+    if (p.Cout % 256 == 0) {
+        const int ntm = (p.M - p.m_begin + 255) / 256;
+        hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4>), dim3(ntm * (p.Cout / 256)), dim3(512), 0, stream, p);
+    } else {  // Cout % 128 == 0: 512 px x 128 cout tiles
+        const int ntm = (p.M - p.m_begin + 511) / 512;
+        hipLaunchKernelGGL((conv_x3_8ph_kernel<4, 2>), dim3(ntm * (p.Cout / 128)), dim3(512), 0, stream, p);
+    }
     return 0;
 }
