@@ -99,6 +99,8 @@ int ufm_debug_set_gemm_variant(int force_small);
 int ufm_debug_set_attn_variant(int v);
 /* Tuning hook for ufm_conv2d_nhwc_bf16x3: 0 = auto, 1 = 128-row kernels only, 2 = 256x256 8-phase kernel wherever applicable. */
 int ufm_debug_set_conv_variant(int v);
+/* Tuning hook for ufm_upsample_bilinear_nhwc (split format): 1 = LDS-tiled kernel where applicable (default), 0 = never. */
+int ufm_debug_set_upsample_variant(int tiled);
 
 /* `ufm infer` post-processing: warp the target image into the source frame with the predicted
  * flow -- [R] utils/viz.py:11-59 warp_image_with_flow: F.grid_sample(bilinear, align_corners=False, zeros padding)

@@ -581,6 +581,27 @@ def test_dpt_tail_fused_bit_identical(hip, B, h, w, H, W, Ct, kinds):
         assert (out.cpu()[:, c].double() - want).abs().max().item() <= 1e-4
 
 
+@pytest.mark.parametrize("B,H,W,C,Ho,Wo,crop", [(2, 19, 23, 64, 38, 46, (0, 0)), (1, 37, 37, 256, 74, 74, (0, 0)), (2, 10, 13, 128, 20, 26, (19, 25)), (1, 40, 33, 64, 70, 58, (0, 0))])
+def test_upsample_split_tiled_bit_identical(hip, B, H, W, C, Ho, Wo, crop):
+    """The LDS-tiled split-format upsample (each source value loaded once per 8x32 tile) against the one-thread-per-output
+    kernel: bit-identical, incl. ragged tiles, the cropped form after refinenet4 and the 296 -> 518-like ratio 0.57."""
+    lib = hip.lib()
+    x = split(rnd(B, H, W, C, seed=1)).to(DEV)
+    Hs, Ws = crop[0] or Ho, crop[1] or Wo
+    outs = []
+    try:
+        for tiled in (0, 1):
+            lib.ufm_debug_set_upsample_variant(tiled)
+            o = torch.full((2, B, Hs, Ws, C), 7.0, device=DEV, dtype=torch.bfloat16)
+            hip.upsample_bilinear(x, B, H, W, C, o, Ho, Wo, crop[0], crop[1])
+            outs.append(o.cpu())
+    finally:
+        lib.ufm_debug_set_upsample_variant(1)
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    ref = F.interpolate(unsplit(x.cpu()).permute(0, 3, 1, 2), size=(Ho, Wo), mode="bilinear", align_corners=True)[:, :, :Hs, :Ws]
+    assert (unsplit(outs[1]).permute(0, 3, 1, 2) - ref).abs().max().item() <= 6e-5 * max(1.0, ref.abs().max().item())
+
+
 def test_split_format_layernorm_upsample_tail(hip):
     rows, D = 37, 128
     x = rnd(rows, D, seed=1, scale=3.0)

@@ -33,6 +33,7 @@ SIGNATURES = {
     "ufm_debug_set_gemm_variant": [_i],
     "ufm_debug_set_attn_variant": [_i],
     "ufm_debug_set_conv_variant": [_i],
+    "ufm_debug_set_upsample_variant": [_i],
     "ufm_warp_bilinear": [_vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _f, _vp, _vp],
     "ufm_dpt_tail_fused": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "ufm_layernorm": [_vp, _i, _vp, _i, _i, _vp, _vp, _f, _vp, _i, _i, _vp],
