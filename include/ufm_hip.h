@@ -145,6 +145,13 @@ int ufm_add_rows(const float* a, int lda, const float* tab, int ldtab, int tab_m
 int ufm_attention_bf16(const uint16_t* qkv, uint16_t* out, int B, int N, int H, float scale,
                        void* stream);
 
+/* Diagnostics for the default ufm_attention_bf16 kernel (scale == 0 form): the same kernel with s_memtime stamps
+ * around the four MFMA/softmax slots of every key tile (cdna_hip_programming.md section 7, "In-kernel stamps").
+ * diag: 8 x uint64 per workgroup = {sync + DMA issue, slot 0, slot 1, slot 2, slot 3, whole kernel (shader cycles),
+ * s_memrealtime ticks (100 MHz) of the whole kernel, key tiles}.  waves = 2 or 4 per workgroup.  Never on the product path. */
+int ufm_debug_attention_stamps(const uint16_t* qkv, uint16_t* out, int B, int N, int H, int waves,
+                               unsigned long long* diag, void* stream);
+
 /* fp32 variant (numerics mode "parity": exact-fp32 MFMA, same tiling). qkv/out are float. */
 int ufm_attention_f32(const float* qkv, float* out, int B, int N, int H, float scale, void* stream);
 

@@ -201,10 +201,10 @@ def test_attention_bf16(hip, B, N, H):
 
 
 @pytest.mark.parametrize("B,N,H", [(1, 17, 1), (2, 100, 2), (2, 1370, 2), (1, 2738, 3), (1, 64, 1), (1, 129, 1)])
-@pytest.mark.parametrize("variant", [0, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_attention_bf16_prescaled_log2_kernel(hip, B, N, H, variant):
-    """scale == 0 path: Q columns pre-multiplied by scale*log2(e) (what the QKV GEMM epilogue does), deferred rescale.
-    variant 0 = v2 (default), 3 = cross-tile pipelined v3 (opt-in)."""
+    """scale == 0 path: Q columns pre-multiplied by scale*log2(e) (what the QKV GEMM epilogue does).
+    variant 0 = 64-rows-per-wave kernel, 4 waves (default), 1 = same with 2 waves per workgroup, 2 = the round-1 kernel."""
     hip.lib().ufm_debug_set_attn_variant(variant)
     qkv = rnd(B * N, 3 * H * 64, seed=N, scale=1.5)
     qkv_b = bf16r(qkv)
@@ -222,7 +222,7 @@ def test_attention_bf16_prescaled_log2_kernel(hip, B, N, H, variant):
     assert err <= 3e-2, err  # + one extra bf16 rounding of the already-rounded test Q (not present in the fused pipeline)
 
 
-@pytest.mark.parametrize("variant", [0, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("growth", [3.0, 30.0])
 def test_attention_bf16_prescaled_deferred_rescale_branches(hip, growth, variant):
     """Late keys whose scores exceed the running reference by less / more than the deferral threshold (rule 26):
@@ -244,6 +244,57 @@ def test_attention_bf16_prescaled_deferred_rescale_branches(hip, growth, variant
         hip.lib().ufm_debug_set_attn_variant(0)
     assert (out.float().cpu().double() - refp).abs().max().item() <= 2e-2
     assert (out.float().cpu().double() - ref).abs().max().item() <= 6e-2
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("growth", [40.0, 400.0])
+def test_attention_bf16_pw_reference_moves(hip, growth, variant):
+    """The 64-rows-per-wave kernel keeps NO running maximum: the reference set at the first key tile only moves when a
+    tile's sum of 2^(s - m_ref) passes 2^64 (or is inf).  Spike keys in the first / a middle / the ragged last tile, for
+    queries of q-block A, q-block B and another wave, at growths that give finite-but-huge sums (40) and inf (400):
+    every row must still match the fp64 softmax (rule 26: full-tensor reference, inputs that FORCE the branch)."""
+    B, N, H = 1, 300, 1
+    c = 0.125 * 1.4426950408889634
+    qkv = bf16r(rnd(N, 192, seed=11, scale=0.5))
+    for key, qrow in ((3, 7), (70, 5), (100, 40), (131, 100), (250, 5), (290, 40), (299, 170), (200, 299)):
+        qkv[key, 64:128] = bf16r(qkv[qrow, :64] * growth)
+    pre = qkv.clone()
+    pre[:, :64] = bf16r(pre[:, :64] * c)
+    refp = attn_ref(torch.cat([pre[:, :64] / c, pre[:, 64:]], 1), B, N, H, 0.125)
+    out = torch.zeros(N, 64, device=DEV, dtype=torch.bfloat16)
+    hip.lib().ufm_debug_set_attn_variant(variant)
+    try:
+        for _ in range(3):
+            hip.attention(pre.to(DEV).bfloat16(), out, B, N, H, 0.0)
+            got = out.float().cpu().double()
+            assert torch.isfinite(got).all()
+            assert (got - refp).abs().max().item() <= 2e-2
+    finally:
+        hip.lib().ufm_debug_set_attn_variant(0)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_attention_bf16_pw_repeatable_full_size(hip, variant):
+    """Race screen for the LDS-DMA ring (counted waits + one barrier per key tile): UFM-Base shapes, repeated launches
+    must agree bit for bit, and with the round-1 kernel to bf16 rounding."""
+    lib = hip.lib()
+    for B, N, H in ((2, 1370, 16), (1, 2738, 12)):
+        qkv = (rnd(B * N, 3 * H * 64, seed=N, scale=1.0)).to(DEV).bfloat16()
+        lib.ufm_debug_set_attn_variant(2)
+        want = torch.zeros(B * N, H * 64, device=DEV, dtype=torch.bfloat16)
+        hip.attention(qkv, want, B, N, H, 0.0)
+        lib.ufm_debug_set_attn_variant(variant)
+        try:
+            first = None
+            for rep in range(5):
+                got = torch.full((B * N, H * 64), 3.0, device=DEV, dtype=torch.bfloat16)
+                hip.attention(qkv, got, B, N, H, 0.0)
+                if first is None:
+                    first = got.clone()
+                    assert (got.float() - want.float()).abs().max().item() <= 4e-2  # 1 bf16 ulp at |O| ~ 4
+                assert torch.equal(got.view(torch.int16), first.view(torch.int16)), rep
+        finally:
+            lib.ufm_debug_set_attn_variant(0)
 
 
 def test_attention_bf16_spike_forces_rescale(hip):

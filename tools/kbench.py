@@ -67,7 +67,7 @@ def main():
             fl = 4.0 * b * h * n * n * 64
             qkv2 = qkv.clone()
             qkv2[:, : h * 64] = (qkv[:, : h * 64].float() * (0.125 * 1.4426950408889634)).bfloat16()
-            for sc, vn, dbg in ((0.125, "v1", 0), (0.0, "v2", 0), (0.0, "v3-pipelined", 3)):
+            for sc, vn, dbg in ((0.0, "pw4", 0), (0.0, "pw2", 1), (0.0, "v2-round1", 2), (0.0, "pw4", 0), (0.0, "pw2", 1), (0.0, "v2-round1", 2)):
                 src = qkv if sc else qkv2
                 lib.ufm_debug_set_attn_variant(dbg)
                 med, mn = timeit(lambda: hip.attention(src, out, b, n, h, sc))

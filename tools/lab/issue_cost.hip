@@ -1,0 +1,99 @@
+// Issue-cost microbenchmark for the attention inner loop (one wave per SIMD, gfx950): what does one MFMA gap cost
+// with the softmax micro-ops of attention_bf16_pw.hip beside it?  Each variant runs REP x 8 gaps between two s_memtime
+// stamps; the program prints the median cycles per gap over all workgroups.  Build + run on the GPU box:
+//   hipcc -O3 --offload-arch=gfx950 tools/lab/issue_cost.hip -o /tmp/issue_cost && /tmp/issue_cost
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define REP 64
+
+// VARIANT bits: 1 = MFMA (AGPR acc), 2 = MFMA with VGPR C/D instead, 4 = 2 x v_exp, 8 = 2 x v_add (two chains),
+// 16 = v_cvt_pk, 32 = one global_load_lds per 4 gaps, 64 = A and B operands from AGPRs, 128: one ds_read_b128 per gap
+template <int V>
+__global__ __launch_bounds__(256, 1) void k(const char* g, unsigned long long* out, float* sink) {
+    __shared__ __attribute__((aligned(16))) char smem[64 * 1024];
+    const int lane = threadIdx.x & 63;
+    f32x16 acc = {0}, accv = {0};
+    bf16x8 a = {1, 2, 3, 4, 5, 6, 7, 8}, b = {8, 7, 6, 5, 4, 3, 2, 1};
+    bf16x8 aa = a, ab = b;
+    float x0 = lane * 0.01f, x1 = lane * 0.02f, s0 = 0.f, s1 = 0.f, e0 = 0.f, e1 = 0.f;
+    unsigned pk = 0;
+    bf16x8 ld = {0};
+    const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)((__attribute__((address_space(3))) void*)(smem)) + (threadIdx.x >> 6) * 1024);
+    unsigned long long t0, t1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    for (int r = 0; r < REP; ++r) {
+#pragma unroll
+        for (int gp = 0; gp < 8; ++gp) {
+            if (V & 1) {
+                if (V & 64) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(aa), "a"(ab));
+                else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+            }
+            if (V & 2) {
+                if (V & 64) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(accv) : "a"(aa), "a"(ab));
+                else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(accv) : "v"(a), "v"(b));
+            }
+            if (V & 4) asm volatile("v_exp_f32 %0, %2\n\tv_exp_f32 %1, %3" : "=v"(e0), "=v"(e1) : "v"(x0), "v"(x1));
+            if (V & 8) asm volatile("v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3" : "+v"(s0), "+v"(s1) : "v"(e0), "v"(e1));
+            if (V & 16) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(e0), "v"(e1));
+            if ((V & 32) && (gp & 3) == 1)
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"((unsigned)(lane * 16 + (r & 63) * 1024)), "s"(g) : "memory");
+            if (V & 128) asm volatile("ds_read_b128 %0, %1" : "=v"(ld) : "v"((unsigned)(lane * 16)));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (V & 32) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (V & 128) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+    float keep = s0 + s1 + e0 + e1 + accv[0] + accv[5] + __uint_as_float(pk) + (float)ld[0];
+    asm volatile("" ::"a"(acc));  // keep the accumulator chain alive
+    if (keep == 123.456f) sink[0] = keep;
+}
+
+template <int V>
+double run(const char* g, unsigned long long* d_out, float* sink, std::vector<unsigned long long>& h) {
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k<V>), dim3(256), dim3(256), 0, 0, g, d_out, sink);
+    hipDeviceSynchronize();
+    hipMemcpy(h.data(), d_out, h.size() * 8, hipMemcpyDeviceToHost);
+    std::sort(h.begin(), h.end());
+    return (double)h[h.size() / 2] / (REP * 8);
+}
+
+int main() {
+    char* g;
+    unsigned long long* d_out;
+    float* sink;
+    hipMalloc(&g, 1 << 20);
+    hipMemset(g, 0, 1 << 20);
+    hipMalloc(&d_out, 256 * 8);
+    hipMalloc(&sink, 64);
+    std::vector<unsigned long long> h(256);
+#define R(V, name) printf("%-58s %7.2f cycles/gap\n", name, run<V>(g, d_out, sink, h));
+    R(1, "mfma (AGPR acc, VGPR A/B)");
+    R(1 | 64, "mfma (AGPR acc, AGPR A/B)");
+    R(2, "mfma (VGPR acc, VGPR A/B)");
+    R(2 | 64, "mfma (VGPR acc, AGPR A/B)");
+    R(4, "2 exp");
+    R(8, "2 add");
+    R(16, "1 cvt_pk");
+    R(4 | 8, "2 exp + 2 add");
+    R(4 | 8 | 16, "2 exp + 2 add + cvt");
+    R(1 | 4, "mfma(A) + 2 exp");
+    R(1 | 8, "mfma(A) + 2 add");
+    R(1 | 4 | 8, "mfma(A) + 2 exp + 2 add");
+    R(1 | 4 | 8 | 16, "mfma(A) + 2 exp + 2 add + cvt");
+    R(2 | 64 | 4 | 8 | 16, "mfma(V acc, A ops) + 2 exp + 2 add + cvt");
+    R(2 | 4 | 8 | 16, "mfma(V acc, V ops) + 2 exp + 2 add + cvt");
+    R(1 | 4 | 8 | 16 | 128, "mfma(A) + 2 exp + 2 add + cvt + ds_read_b128");
+    R(1 | 4 | 8 | 16 | 32, "mfma(A) + 2 exp + 2 add + cvt + glds/4 gaps");
+    R(32, "glds/4 gaps alone");
+    R(1 | 32, "mfma(A) + glds/4 gaps");
+    return 0;
+}

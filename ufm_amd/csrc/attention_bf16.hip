@@ -678,6 +678,8 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel_v3(const uint16_t* __
 
 }  // namespace
 
+int ufm_launch_attn_pw(const uint16_t* qkv, uint16_t* out, int B, int N, int H, int variant, hipStream_t stream);  // attention_bf16_pw.hip
+
 static int g_attn_debug = 0;
 extern "C" int ufm_debug_set_attn_variant(int v) {
     g_attn_debug = v;
@@ -689,7 +691,9 @@ extern "C" int ufm_attention_bf16(const uint16_t* qkv, uint16_t* out, int B, int
     UFM_REQUIRE(B > 0 && N > 0 && H > 0 && (int64_t)((N + QB - 1) / QB) * H * B < (1ll << 31), "ufm_attention_bf16: bad shape B=%d N=%d H=%d", B, N, H);
     UFM_REQUIRE(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 8) == 0, "ufm_attention_bf16: misaligned pointer");
     dim3 grid(((N + QB - 1) / QB) * H * B), block(256);
-    if (scale == 0.0f && g_attn_debug == 3)  // opt-in: cross-tile pipelined v3 (+3..10 % on randn data in tools/kbench.py,
+    if (scale == 0.0f && (g_attn_debug == 0 || g_attn_debug == 1))  // default: 64 rows per wave, one wave per SIMD (0: 4 waves, 1: 2 waves per workgroup)
+        ufm_launch_attn_pw(qkv, out, B, N, H, g_attn_debug, (hipStream_t)stream);
+    else if (scale == 0.0f && g_attn_debug == 3)  // opt-in: cross-tile pipelined v3 (+3..10 % on randn data in tools/kbench.py,
                                              // but 26 % SLOWER inside the real pipeline: 8.9 vs 6.6 ms per step)
         hipLaunchKernelGGL(attn_bf16_kernel_v3, grid, block, 0, (hipStream_t)stream, qkv, out, N, H);
     else if (scale == 0.0f)  // Q pre-scaled by softmax_scale*log2(e): scores already in log2 units

@@ -41,6 +41,7 @@ SIGNATURES = {
     "ufm_add_rows": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp],
     "ufm_attention_bf16": [_vp, _vp, _i, _i, _i, _f, _vp],
     "ufm_attention_f32": [_vp, _vp, _i, _i, _i, _f, _vp],
+    "ufm_debug_attention_stamps": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "ufm_conv2d_nhwc_f32": [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp],
     "ufm_conv2d_nhwc_bf16x3": [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "ufm_upsample_bilinear_nhwc": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp],
