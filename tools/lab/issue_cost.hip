@@ -15,7 +15,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // VARIANT bits: 1 = MFMA (AGPR acc), 2 = MFMA with VGPR C/D instead, 4 = 2 x v_exp, 8 = 2 x v_add (two chains),
 // 16 = v_cvt_pk, 32 = one global_load_lds per 4 gaps, 64 = A and B operands from AGPRs, 128: one ds_read_b128 per gap
 template <int V>
-__global__ __launch_bounds__(256, 1) void k(const char* g, unsigned long long* out, float* sink) {
+__global__ __launch_bounds__(1024) void k(const char* g, unsigned long long* out, float* sink) {
     __shared__ __attribute__((aligned(16))) char smem[64 * 1024];
     const int lane = threadIdx.x & 63;
     f32x16 acc = {0}, accv = {0};
@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256, 1) void k(const char* g, unsigned long long* o
     bf16x8 aa = a, ab = b;
     float x0 = lane * 0.01f, x1 = lane * 0.02f, s0 = 0.f, s1 = 0.f, e0 = 0.f, e1 = 0.f;
     unsigned pk = 0;
-    bf16x8 ld = {0};
+    bf16x8 ld = {0}, ldv[8];
     const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)((__attribute__((address_space(3))) void*)(smem)) + (threadIdx.x >> 6) * 1024);
     unsigned long long t0, t1;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
@@ -43,23 +43,36 @@ __global__ __launch_bounds__(256, 1) void k(const char* g, unsigned long long* o
             if (V & 16) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(e0), "v"(e1));
             if ((V & 32) && (gp & 3) == 1)
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"((unsigned)(lane * 16 + (r & 63) * 1024)), "s"(g) : "memory");
-            if (V & 128) asm volatile("ds_read_b128 %0, %1" : "=v"(ld) : "v"((unsigned)(lane * 16)));
+            if (V & 128) asm volatile("ds_read_b128 %0, %1" : "=v"(ldv[gp]) : "v"((unsigned)(lane * 16 + gp * 1024)));
             __builtin_amdgcn_sched_barrier(0);
         }
         if (V & 32) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        if (V & 128) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (V & 128) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ld[0] ^= ldv[q][0];
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+    if (lane == 0) {  // block time = first start .. last end over its waves (older waves win issue arbitration)
+        __shared__ unsigned long long tmin, tmax;
+        if (threadIdx.x == 0) { tmin = ~0ull; tmax = 0; }
+        __builtin_amdgcn_s_barrier();
+        atomicMin(&tmin, t0);
+        atomicMax(&tmax, t1);
+        __builtin_amdgcn_s_barrier();
+        if (threadIdx.x == 0) out[blockIdx.x] = tmax - tmin;
+    }
     float keep = s0 + s1 + e0 + e1 + accv[0] + accv[5] + __uint_as_float(pk) + (float)ld[0];
     asm volatile("" ::"a"(acc));  // keep the accumulator chain alive
     if (keep == 123.456f) sink[0] = keep;
 }
 
+static int g_threads = 256;
 template <int V>
 double run(const char* g, unsigned long long* d_out, float* sink, std::vector<unsigned long long>& h) {
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k<V>), dim3(256), dim3(256), 0, 0, g, d_out, sink);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k<V>), dim3(256), dim3(g_threads), 0, 0, g, d_out, sink);
     hipDeviceSynchronize();
     hipMemcpy(h.data(), d_out, h.size() * 8, hipMemcpyDeviceToHost);
     std::sort(h.begin(), h.end());
@@ -76,6 +89,18 @@ int main() {
     hipMalloc(&sink, 64);
     std::vector<unsigned long long> h(256);
 #define R(V, name) printf("%-58s %7.2f cycles/gap\n", name, run<V>(g, d_out, sink, h));
+    for (int thr : {512, 1024}) {  // 2 and 4 waves per SIMD: cycles per gap PER WAVE
+        g_threads = thr;
+        printf("-- %d waves per SIMD --\n", thr / 256);
+        R(1, "mfma (AGPR acc)");
+        R(4 | 8 | 16, "2 exp + 2 add + cvt");
+        R(1 | 4 | 8 | 16, "mfma(A) + 2 exp + 2 add + cvt");
+        R(2 | 4 | 8 | 16, "mfma(V acc) + 2 exp + 2 add + cvt");
+        R(4, "2 exp");
+        R(8, "2 add");
+    }
+    g_threads = 256;
+    printf("-- 1 wave per SIMD --\n");
     R(1, "mfma (AGPR acc, VGPR A/B)");
     R(1 | 64, "mfma (AGPR acc, AGPR A/B)");
     R(2, "mfma (VGPR acc, VGPR A/B)");
