@@ -19,6 +19,10 @@ Rank 0 prints ONE JSON line.  Extra objects:
   cpu_baseline  the fp32 CPU oracle (a port; the reference's own CPU path cannot run, its
                 arithmetic lives in an absent package) timed on this box's host cores on a
                 bounded sample (rank 0, N=1 only).
+  parity_mode   the SAME workload in numerics "parity" (exact-fp32 MFMA everywhere, the mode that meets the
+                1e-3 px gate): pairs/s, ms/step and its flow max-abs vs the oracle (rank 0, N=1 only).
+  latency_b1_ms single-pair p50 latency (BASELINE metric "pairs/s + p50 latency"): eager launches and
+                HIP-graph replay (ufm_amd.GraphedPredictor).
 """
 
 import argparse
@@ -51,6 +55,33 @@ def host_cores() -> int:
     return max(1, min(n, 16))
 
 
+def csrc_sha256() -> str:
+    """Content hash of ufm_amd/csrc (same function as tools/pmc_summarize.py): ties the PMC traffic summary to the
+    kernel sources it was measured on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "ufm_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+def p50_ms(fn, iters: int, warm: int) -> float:
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append(1e3 * (time.perf_counter() - t0))
+    return sorted(ts)[len(ts) // 2]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -61,6 +92,8 @@ def main():
     ap.add_argument("--numerics", default="fast", choices=["fast", "parity"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-parity-mode", action="store_true", help="skip the extra numerics='parity' timing of the same workload")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-pair latency measurement")
     ap.add_argument("--gemm-variant", type=int, default=0, help="tuning hook: ufm_debug_set_gemm_variant (0 = auto)")
     ap.add_argument("--attn-variant", type=int, default=0, help="tuning hook: ufm_debug_set_attn_variant (0 = default)")
     ap.add_argument("--concurrent-heads", action="store_true", help="run the two DPT heads on separate streams (measured: no gain)")
@@ -99,38 +132,37 @@ def main():
     model.engine().concurrent_heads = args.concurrent_heads
 
     B = args.batch
-    g = torch.Generator().manual_seed(1234 + rank)  # each rank owns its own slice of the global batch
-    src = torch.randint(0, 256, (B, res, res, 3), dtype=torch.uint8, generator=g).to(dev)
-    tgt = torch.randint(0, 256, (B, res, res, 3), dtype=torch.uint8, generator=g).to(dev)
-    # Result gather (the only collective): ONE RCCL all_gather per step of the packed [flow | covisibility] buffer, issued
-    # asynchronously and double-buffered so that step i's gather (xGMI) overlaps step i+1's compute; every gather is
-    # waited for inside the timed region (the slot is reused two steps later, and drain() runs before the closing fence).
-    gathered = [torch.empty((world * B, 3, res, res), device=dev) for _ in range(2)] if use_dist else None
-    packed = [torch.empty((B, 3, res, res), device=dev) for _ in range(2)] if use_dist else None
-    pending = [None, None]
-    counter = [0]
+    # Global batch = world x B pairs, generated identically on every rank (one seeded CPU stream); each rank computes
+    # its contiguous shard and ONE RCCL all_gather per step closes it (ufm_amd.dist.ShardedPredictor: the class the
+    # gloo world_size 2/3 CPU tests and the nccl GPU test exercise).  The gather is asynchronous over a ring of two
+    # buffers: step i's gather (xGMI) overlaps step i+1's compute, and every gather is waited for inside the timed
+    # region (result() of the previous step each step, drain() before the closing fence).
+    g = torch.Generator().manual_seed(1234)
+    src = torch.randint(0, 256, (world * B, res, res, 3), dtype=torch.uint8, generator=g).to(dev)
+    tgt = torch.randint(0, 256, (world * B, res, res, 3), dtype=torch.uint8, generator=g).to(dev)
+    sharded = None
+    if use_dist:
+        from ufm_amd.dist import ShardedPredictor, shard_bounds
+
+        def predict_pair_batch(s_, t_):
+            o_ = model.predict_correspondences_batched(s_, t_)
+            return o_.flow.flow_output, o_.covisibility.mask
+
+        sharded = ShardedPredictor(predict_pair_batch, depth=2)
+    last = [None]
 
     def step():
-        out = model.predict_correspondences_batched(src, tgt)
-        if use_dist:
-            s = counter[0] & 1
-            counter[0] += 1
-            if pending[s] is not None:
-                pending[s].wait()  # stream-level: the buffers of two steps ago are free again
-            packed[s][:, :2].copy_(out.flow.flow_output)
-            packed[s][:, 2].copy_(out.covisibility.mask)
-            pending[s] = dist.all_gather_into_tensor(gathered[s], packed[s], async_op=True)
-        return out
-
-    def drain():
-        for s in range(2):
-            if pending[s] is not None:
-                pending[s].wait()
-                pending[s] = None
+        if sharded is None:
+            return model.predict_correspondences_batched(src, tgt)
+        tk = sharded.submit(src, tgt)
+        if last[0] is not None:
+            sharded.wait(last[0])  # the previous step's gathered results are complete (stream-level wait)
+        last[0] = tk
+        return tk
 
     def fence():
         if use_dist:
-            drain()
+            sharded.drain()
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -173,11 +205,23 @@ def main():
             "global_batch": world * B,
             "resolution": res,
             "numerics": f"{args.numerics}: " + ("bf16 MFMA trunk (fp32 accumulate/residual/LN/softmax stats), DPT heads in bf16x3 split precision (~2^-17 rel., fp32 accumulate)" if args.numerics == "fast" else "fp32 MFMA everywhere"),
-            "parallelism": f"dp{world} (pair-batch split; one async double-buffered RCCL all_gather of the results per step)",
+            "parallelism": f"dp{world} (pair-batch split; one async double-buffered RCCL all_gather of the results per step, ufm_amd.dist.ShardedPredictor)",
             "micro_batches_per_gpu": args.micro_batches,
         },
     }
 
+    # ---- N > 1: the gathered result of ANOTHER rank's shard equals this rank's own recomputation, bit for bit ----
+    if use_dist:
+        flow_all, mask_all = sharded.result(last[0])
+        lo, _ = shard_bounds(world * B, (rank + 1) % world, world)
+        mine = model.predict_correspondences_batched(src[lo : lo + 1], tgt[lo : lo + 1])
+        same = bool(torch.equal(mine.flow.flow_output, flow_all[lo : lo + 1]) and torch.equal(mine.covisibility.mask, mask_all[lo : lo + 1]))
+        ok = torch.tensor([1 if same else 0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        line["gather_check"] = {"bitwise_equal_to_local_recompute": bool(ok.item()), "pairs_gathered": int(flow_all.shape[0])}
+        assert bool(ok.item()), "gathered results differ from the local recomputation"
+
+    src, tgt = src[:B], tgt[:B]  # everything below is single-GPU work on one shard-sized batch
     # ---- per-kernel durations: one extra instrumented step, HIP events on the launch stream ----
     if rank == 0 and not args.no_kernel_timing:
         hip.TIMER = hip.KernelTimer()
@@ -202,17 +246,23 @@ def main():
         # HBM traffic per launch: PMC counters cannot be read from inside the process; they come from the committed
         # summary of `tools/pmc_traffic.sh` (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc passes over
         # this same command), averaged over the launches of the family like `achieved`.
-        pmc = {}
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_step_summary.json")
+        pmc, traffic_src = {}, None
+        pmc_path = os.path.join(ROOT, "profiles", "r02", "pmc_step_summary.json")
         if os.path.exists(pmc_path) and B == 8 and res == 518 and args.numerics == "fast":
-            pmc = json.load(open(pmc_path))
+            cand = json.load(open(pmc_path))
+            meta = cand.get("_meta", {})
+            # counters measured on other kernel sources are not evidence for this run: drop them (traffic = null)
+            if meta.get("csrc_sha256") == csrc_sha256():
+                pmc, traffic_src = cand, {"file": "profiles/r02/pmc_step_summary.json", "csrc_sha256": meta["csrc_sha256"], "commit": meta.get("commit_at_summarise_time")}
+            else:
+                traffic_src = {"file": "profiles/r02/pmc_step_summary.json", "stale": True, "measured_on_csrc_sha256": meta.get("csrc_sha256"), "this_tree": csrc_sha256()}
         for k, v in kernels.items():
             if k in pmc and "hbm_bytes_per_step" in pmc[k]:
                 v["traffic"] = pmc[k]["hbm_bytes_per_step"] / v["launches"]  # per C-ABI call, like `achieved`
                 v["mfma_busy_frac_pmc"] = pmc[k].get("mfma_busy_frac")
         line["roofline"] = {
             "kernel": dom, "bound": "mfma", "achieved": d["achieved"], "peak": d["peak"], "unit": "TFLOP/s", "frac": d["frac"],
-            "traffic": d.get("traffic"), "traffic_unit": "HBM bytes per launch (PMC, profiles/r01/pmc_step_summary.json)",
+            "traffic": d.get("traffic"), "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
             "avg_launch_us": d["avg_launch_us"], "algorithmic_gflop_per_launch": d["algorithmic_gflop"] / d["launches"],
         }
         if "ufm_attention_bf16" in kernels:
@@ -222,6 +272,7 @@ def main():
         line["instrumented_step_ms"] = sum(v["ms_per_step"] for v in kernels.values())
 
     # ---- CPU baseline: the oracle on this box's host cores, bounded sample ----
+    ref_oracle = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import ufm_ref as R
 
@@ -240,11 +291,47 @@ def main():
             "value": 1.0 / cpu_s, "unit": "pairs/s", "cores": ncores, "kind": "port",
             "sample": f"1 pair of the same workload ({res}x{res}, same weights), fp32 eager-PyTorch oracle, {cpu_s:.1f} s",
         }
+        ref_oracle = ref
         line["check_vs_oracle"] = {
+            "numerics": args.numerics,
             "flow_max_abs": float((got.flow.flow_output.cpu() - ref.flow.flow_output).abs().max()),
             "flow_range": float(ref.flow.flow_output.abs().max()),
             "covis_max_abs": float((got.covisibility.mask.cpu() - ref.covisibility.mask).abs().max()),
         }
+
+    # ---- single-pair latency (BASELINE metric: "pairs/s + p50 latency"): wall clock of one synchronous call ----
+    if rank == 0 and not args.no_latency:
+        s1d, t1d = src[:1].contiguous(), tgt[:1].contiguous()
+        eager = p50_ms(lambda: model.predict_correspondences_batched(s1d, t1d), 20, 3)
+        lat = {"eager_p50": eager, "iters": 20, "batch": 1}
+        try:
+            gp = ufm_amd.GraphedPredictor(model, s1d, t1d)
+            lat["graph_replay_p50"] = p50_ms(lambda: gp(s1d, t1d), 20, 3)
+            a_ = model.predict_correspondences_batched(s1d, t1d).flow.flow_output.clone()
+            lat["graph_bitwise_equals_eager"] = bool(torch.equal(gp(s1d, t1d).flow.flow_output, a_))
+        except Exception as exc:  # reported, not fatal: the eager number stands on its own
+            lat["graph_error"] = repr(exc)[:200]
+        line["latency_b1_ms"] = lat
+
+    # ---- the same workload in numerics "parity" (exact-fp32 MFMA everywhere: the mode that meets the 1e-3 px gate) ----
+    if rank == 0 and world == 1 and args.numerics == "fast" and not args.no_parity_mode:
+        model.set_numerics("parity")
+        model.engine().micro_batches = args.micro_batches
+        model.predict_correspondences_batched(src, tgt)
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        for _ in range(3):
+            model.predict_correspondences_batched(src, tgt)
+        torch.cuda.synchronize()
+        par_s = (time.perf_counter() - c0) / 3
+        pm = {"value": B / par_s, "unit": "pairs/s", "ms_per_step": 1e3 * par_s, "steps": 3, "dtype": "f32",
+              "numerics": "parity: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) for every contraction"}
+        if ref_oracle is not None:
+            gotp = model.predict_correspondences_batched(src[:1], tgt[:1])
+            pm["flow_max_abs"] = float((gotp.flow.flow_output.cpu() - ref_oracle.flow.flow_output).abs().max())
+            pm["covis_max_abs"] = float((gotp.covisibility.mask.cpu() - ref_oracle.covisibility.mask).abs().max())
+        line["parity_mode"] = pm
+        model.set_numerics("fast")
 
     if rank == 0:
         print(json.dumps(line))

@@ -201,7 +201,7 @@ int ufm_upsample_bilinear_nhwc(const void* in, int dtype /* UFM_F32 | UFM_BF16X2
  * ([U] DPTRegressionProcessor.conv2[2] + FlowAdaptor / MaskAdaptor; call sites
  * models/ufm.py:644-660).  kind[c]: 0 = affine y*a[c]+d[c] (FlowAdaptor), 1 = sigmoid
  * (MaskAdaptor: writes mask to out, logits to out_logits if non-NULL).
- * x: fp32 [P][Cin] -> out: fp32 planar [B][Cout][HW] (P = B*HW). Cout <= 4. */
+ * x: fp32 [P][Cin] -> out: fp32 planar [B][Cout][HW] (P = B*HW). Cout <= 8. */
 int ufm_head_tail(const void* x, int in_dtype /* UFM_F32 | UFM_BF16X2 */, int P, int HW, int Cin,
                   const float* w, const float* b, int Cout,
                   const int32_t* kind_host, const float* a_host, const float* d_host, float* out,
@@ -209,7 +209,7 @@ int ufm_head_tail(const void* x, int in_dtype /* UFM_F32 | UFM_BF16X2 */, int P,
 
 /* The whole full-resolution tail of [U] DPTRegressionProcessor in numerics "fast", fused:
  * bilinear(align_corners=True) (h, w) -> (H, W)  ->  conv 3x3 pad 1 (Cin = 128 -> Cmid = 32) + bias + ReLU  ->
- * conv 1x1 (32 -> Ct <= 4) + bias  ->  Flow/Mask adaptor (as ufm_head_tail; call sites models/ufm.py:644-660).
+ * conv 1x1 (32 -> Ct <= 8) + bias  ->  Flow/Mask adaptor (as ufm_head_tail; call sites models/ufm.py:644-660).
  * in: UFM_BF16X2 [2][B][h][w][128]; w2: UFM_BF16X2 [2][32][3][3][128]; out (and out_logits): fp32 planar
  * [B][Ct][H][W].  Bit-identical to ufm_upsample_bilinear_nhwc -> ufm_conv2d_nhwc_bf16x3(act = ReLU) ->
  * ufm_head_tail, without the two full-resolution intermediate maps ever reaching HBM. */
@@ -217,6 +217,17 @@ int ufm_dpt_tail_fused(const uint16_t* in, int B, int h, int w, int Cin, const u
                        int Cmid, int H, int W, const float* wt, const float* bt, int Ct,
                        const int32_t* kind_host, const float* a_host, const float* d_host, float* out,
                        float* out_logits, void* stream);
+
+/* Output adaptors that are not a per-channel affine / sigmoid ([U] uniception prediction_heads.adaptors; the
+ * uncertainty head's optional branches, call sites models/ufm.py:648-654).  `raw` = the decoded channels as written by
+ * ufm_head_tail / ufm_dpt_tail_fused with kind 0, a = 1, d = 0.
+ *   Covariance2DAdaptor: raw planar [B][3][HW] = (log sigma_x, log sigma_y, atanh-like rho) ->
+ *     covariance [B][3][HW] = (xx, yy, xy) with rho = 0.99 tanh(r); inverse covariance [B][3][HW]; log-determinant [B][1][HW]
+ *     (-> UFMFlowFieldOutput.flow_covariance / _inv / _log_det, ufm.py:648-651).
+ *   ConfidenceAdaptor (keypoint_confidence, ufm.py:653-654): type 0 = min(vmin + exp(x), vmax), 1 = (vmax-vmin) sigmoid(x) + vmin,
+ *     2 = identity. */
+int ufm_adaptor_covariance2d(const float* raw, int B, int HW, float* cov, float* inv_cov, float* log_det, void* stream);
+int ufm_adaptor_confidence(const float* raw, int64_t n, int type, float vmin, float vmax, float* out, void* stream);
 
 /* =====================================================================================
  * Post-processing (utils/flow_resizing.py:749-877 unmap_predicted_flow and :955-1010
@@ -242,6 +253,28 @@ int ufm_unmap_channels(const float* chan, int B, int C, int h, int w, const int3
 int ufm_refine(const float* flow, const float* feat, int B, int C, int H, int W, int P,
                float temperature, const float* bias, float* residual, float* log_softmax,
                void* stream);
+
+/* =====================================================================================
+ * UNet fine-feature path of UFM-Refine (models/unet_encoder.py:26-71, use_unet_feature=True: models/ufm.py:816-825,
+ * :915-917, :967-983).  The UNet's convolutions run on ufm_conv2d_nhwc_f32 / ufm_conv2d_nhwc_bf16x3 (3x3 pad 1 + ReLU,
+ * ConvTranspose2d(k=s=2) in shuffle mode, 1x1); these are the layout moves in between, all on NHWC fp32 or UFM_BF16X2.
+ *   ufm_image_to_nhwc:       the normalised network-resolution image (same in_dtype/in_layout/scale3/shift3 convention as
+ *                            ufm_patchify) as NHWC with the 3 channels zero-padded to Cpad (the conv kernels' K chunk)
+ *   ufm_maxpool2x2_nhwc:     nn.MaxPool2d(2, 2) (unet_encoder.py:37,57); out [B][H/2][W/2][C]
+ *   ufm_resize_nearest_nhwc: F.interpolate(x, size=(Ho, Wo)) in the default legacy "nearest" mode (unet_encoder.py:66-67),
+ *                            written into channels [c_off, c_off + C) of an output with ldc channels per pixel -- the
+ *                            torch.cat((skip, x), dim=1) slot of unet_encoder.py:68 (Ho == H, Wo == W: a plain copy)
+ *   ufm_unet_combine:        per pixel, cls = MLPFeature features planar [N][16][HW], unet = NHWC [N][HW][ldu] (16 used):
+ *                            method 0 "conv": conv2(relu(conv1(cat[cls, unet])))  (w1 [32][32], w2 [16][32]);
+ *                            method 1 "modulate": conv2(cls * tanh(unet))        (w2 [16][16]); out planar [N][16][HW].
+ * ===================================================================================== */
+int ufm_image_to_nhwc(const void* img, int in_dtype, int in_layout, int B, int H, int W, const float* scale3,
+                      const float* shift3, void* out, int out_dtype, int Cpad, void* stream);
+int ufm_maxpool2x2_nhwc(const void* in, int dtype, int B, int H, int W, int C, void* out, void* stream);
+int ufm_resize_nearest_nhwc(const void* in, int dtype, int B, int H, int W, int C, void* out, int Ho, int Wo, int ldc,
+                            int c_off, void* stream);
+int ufm_unet_combine(const float* cls, const void* unet, int unet_dtype, int N, int HW, int ldu, const float* w1,
+                     const float* b1, const float* w2, const float* b2, int method, float* out, void* stream);
 
 /* Pixel shuffle for MLPFeature ([U], call site models/ufm.py:965): x fp32 [B*g*g][C*p*p]
  * (column = (c, i, j)) -> planar [B][C][g*p][g*p]. */

@@ -237,6 +237,61 @@ _ADAPTORS = {
 }
 
 
+# --------------------------------------------------------------------------- #
+# UNet fine-feature encoder: models/unet_encoder.py:10-71 (PINNED: tests/golden/unet_*.npz are outputs of the
+# reference's own class, which loads standalone)
+# --------------------------------------------------------------------------- #
+
+
+class DoubleConvRef(nn.Module):
+    """unet_encoder.py:10-23: (Conv3x3 pad 1 -> ReLU) x 2."""
+
+    def __init__(self, cin: int, cout: int):
+        super().__init__()
+        self.conv = nn.Sequential(
+            nn.Conv2d(cin, cout, kernel_size=3, padding=1), nn.ReLU(inplace=True), nn.Conv2d(cout, cout, kernel_size=3, padding=1), nn.ReLU(inplace=True)
+        )
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.conv(x)
+
+
+class UNetRef(nn.Module):
+    """unet_encoder.py:26-71.  Same attribute names, hence the same state-dict keys (downs.N.conv.{0,2}, ups.{2k} =
+    ConvTranspose2d(k=s=2), ups.{2k+1} = DoubleConv, bottleneck, final_conv)."""
+
+    def __init__(self, in_channels: int, out_channels: int, features: Sequence[int] = (64, 128, 256, 512)):
+        super().__init__()
+        self.downs, self.ups = nn.ModuleList(), nn.ModuleList()
+        c = in_channels
+        for f in features:
+            self.downs.append(DoubleConvRef(c, f))
+            c = f
+        self.pool = nn.MaxPool2d(kernel_size=2, stride=2)
+        self.bottleneck = DoubleConvRef(features[-1], features[-1] * 2)
+        for f in reversed(features):
+            self.ups.append(nn.ConvTranspose2d(f * 2, f, kernel_size=2, stride=2))
+            self.ups.append(DoubleConvRef(f * 2, f))
+        self.final_conv = nn.Conv2d(features[0], out_channels, kernel_size=1)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        skips = []
+        for down in self.downs:  # :53-57
+            x = down(x)
+            skips.append(x)
+            x = self.pool(x)
+        x = self.bottleneck(x)
+        skips = skips[::-1]
+        for i in range(0, len(self.ups), 2):  # :62-69
+            x = self.ups[i](x)
+            skip = skips[i // 2]
+            if x.shape != skip.shape:  # odd sizes: legacy "nearest" resize to the skip's size (:66-67)
+                x = F.interpolate(x, size=skip.shape[2:])
+            x = torch.cat((skip, x), dim=1)
+            x = self.ups[i + 1](x)
+        return self.final_conv(x)
+
+
 def _make_head(head_type: str, feature_head_kwargs: Dict[str, Any], adaptors_kwargs: Dict[str, Any]) -> nn.Module:
     """ufm.py:243-289."""
     assert head_type == "dpt", "oracle restates the dpt head only"
@@ -267,6 +322,8 @@ class UFMRef(nn.Module):
         temperature: float = 4.0,
         refinement_range: int = 5,
         inference_resolution: Any = (560, 420),
+        use_unet_feature: bool = False,
+        feature_combine_method: str = "conv",
         **_: Any,
     ):
         super().__init__()
@@ -284,6 +341,15 @@ class UFMRef(nn.Module):
             self.classification_head = U.MLPFeature(**classification_head_kwargs)
             self.refinement_range = refinement_range
             self.temperature = temperature
+            self.use_unet_feature = use_unet_feature
+            self.feature_combine_method = feature_combine_method
+            if use_unet_feature:  # ufm.py:816-825
+                self.unet_feature = UNetRef(in_channels=3, out_channels=16, features=[64, 128, 256, 512])
+                self.conv1 = nn.Conv2d(32, 32, kernel_size=1)
+                if feature_combine_method == "conv":
+                    self.conv2 = nn.Conv2d(32, 16, kernel_size=1)
+                elif feature_combine_method == "modulate":
+                    self.conv2 = nn.Conv2d(16, 16, kernel_size=1)
             self.classification_bias = nn.Parameter(torch.zeros(refinement_range * refinement_range))
 
     @torch.no_grad()
@@ -293,10 +359,14 @@ class UFMRef(nn.Module):
         if img1.shape[-2:] != img2.shape[-2:]:
             raise NotImplementedError("Unequal Image sizes are not supported now")  # ufm.py:316-317
         shape1 = (int(img1.shape[2]), int(img1.shape[3]))
-        enc = self.encoder(U.ViTEncoderInput(image=torch.cat((img1, img2), dim=0), data_norm_type=self.encoder.data_norm_type))
-        f1 = [e.features.chunk(2, dim=0)[0] for e in enc]
-        f2 = [e.features.chunk(2, dim=0)[1] for e in enc]
-        final, inter = self.info_sharing(U.MultiViewTransformerInput(features=[f1[-1], f2[-1]]))
+        # ``autocast_bf16``: emulate the reference's GPU precision policy on the CPU -- trunk under bf16 autocast
+        # (base.py:273), heads and refinement in the fp32 island (ufm.py:635).  Used only to measure how far the
+        # reference's OWN bf16 policy moves the outputs (tests/test_model_gpu.py); the default is the fp32 CPU path.
+        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=bool(getattr(self, "autocast_bf16", False))):
+            enc = self.encoder(U.ViTEncoderInput(image=torch.cat((img1, img2), dim=0), data_norm_type=self.encoder.data_norm_type))
+            f1 = [e.features.chunk(2, dim=0)[0] for e in enc]
+            f2 = [e.features.chunk(2, dim=0)[1] for e in enc]
+            final, inter = self.info_sharing(U.MultiViewTransformerInput(features=[f1[-1], f2[-1]]))
         # ufm.py:602-608: only the view-1 pyramid is ever decoded (:637-641, :698-700)
         pyr1 = [f1[-1].float(), inter[0].features[0].float(), inter[1].features[0].float(), final.features[0].float()]
         out = Out()
@@ -310,12 +380,20 @@ class UFMRef(nn.Module):
                 out.flow.flow_covariance = hu["flow_cov"].covariance
                 out.flow.flow_covariance_inv = hu["flow_cov"].inv_covariance
                 out.flow.flow_covariance_log_det = hu["flow_cov"].log_det
+            if "keypoint_confidence" in hu:  # ufm.py:653-654 (attached dynamically)
+                out.keypoint_confidence = hu["keypoint_confidence"].value.squeeze(1)
             if "non_occluded_mask" in hu:
                 out.covisibility = MaskOut(mask=hu["non_occluded_mask"].mask, logits=hu["non_occluded_mask"].logits)
         if self.refine:  # ufm.py:949-1007
             c1 = torch.cat([f1[0].float(), pyr1[-1]], dim=1)
             c2 = torch.cat([f2[0].float(), final.features[1].float()], dim=1)
             cf = self.classification_head(U.PredictionHeadInput(torch.cat([c1, c2], dim=0))).decoded_channels
+            if getattr(self, "use_unet_feature", False):  # ufm.py:915-917, :967-983
+                un = torch.cat([self.unet_feature(img1), self.unet_feature(img2)], dim=0)
+                if self.feature_combine_method == "conv":
+                    cf = self.conv2(F.relu(self.conv1(torch.cat([cf, un], dim=1))))
+                elif self.feature_combine_method == "modulate":
+                    cf = self.conv2(cf * torch.tanh(un))
             residual, logp = classification_refinement(flow, cf, self.refinement_range, self.temperature, self.classification_bias)
             flow = flow + residual
             out.flow.flow_output = flow
@@ -369,6 +447,8 @@ def make_config(
     refine: bool = False,
     refine_dim: int = 16,
     enc_init_values: Optional[float] = 1.0,
+    use_unet_feature: bool = False,
+    feature_combine_method: str = "conv",
 ) -> Dict[str, Any]:
     dpt = dict(
         dpt_feature=dict(
@@ -422,6 +502,9 @@ def make_config(
         )
         cfg["temperature"] = 4.0
         cfg["refinement_range"] = 5
+        if use_unet_feature:
+            cfg["use_unet_feature"] = True
+            cfg["feature_combine_method"] = feature_combine_method
     return cfg
 
 
@@ -429,9 +512,10 @@ def ufm_base_config(resolution_wh: Tuple[int, int] = (518, 518)) -> Dict[str, An
     return make_config(resolution_wh=resolution_wh)
 
 
-def ufm_tiny_config(resolution_wh: Tuple[int, int] = (56, 56), refine: bool = False) -> Dict[str, Any]:
+def ufm_tiny_config(resolution_wh: Tuple[int, int] = (56, 56), refine: bool = False, **kw: Any) -> Dict[str, Any]:
     """Small enough for second-scale CPU tests; same topology (all dims multiples of 64 for the kernels)."""
     return make_config(
+        **kw,
         enc_dim=128,
         enc_depth=3,
         enc_heads=2,

@@ -108,11 +108,12 @@ def main():
 
     # ------------------------------------------------------------------ glue
     class FakeModel(ref_base.UniFlowMatchModelsBase):
-        def __init__(self, res, seed):
+        def __init__(self, res, seed, with_cov=False):
             super().__init__(inference_resolution=res)
             self.encoder = SimpleNamespace(data_norm_type="dinov2")
             self.seed = seed
             self.seen = None
+            self.with_cov = with_cov
 
         def forward(self, view1, view2):
             self.seen = (view1["img"].clone(), view2["img"].clone())
@@ -120,6 +121,10 @@ def main():
             fl, mask = analytic_fields(b, h, w, self.seed)
             out = ref_base.UFMOutputInterface()
             out.flow = ref_base.UFMFlowFieldOutput(flow_output=fl)
+            if self.with_cov:  # base.py:295-319: the covariance is un-mapped and rescaled by [wr^2, hr^2, wr*hr]
+                gc = torch.Generator().manual_seed(self.seed + 1000)
+                out.flow.flow_covariance = torch.rand(b, 3, h, w, generator=gc) + 0.1 * fl[:, :1].abs()
+                self.cov_in = out.flow.flow_covariance.clone()
             out.covisibility = ref_base.UFMMaskFieldOutput(mask=mask, logits=mask * 0)
             return out
 
@@ -131,6 +136,8 @@ def main():
         ("up_f32_bchw", (70, 56), (30, 40), (33, 47), "bchw", "f32", True),
         ("multi_res", [(56, 42), (42, 56), (56, 56)], (120, 70), (110, 80), "bhwc", "u8", True),
         ("renorm_f32", (56, 56), (64, 48), (64, 48), "bchw", "f32_dust3r", True),
+        ("cov_down_u8", (56, 42), (75, 100), (60, 90), "bhwc", "u8", True),   # flow_covariance branch, base.py:295-319
+        ("cov_ident_u8", (56, 56), (56, 56), (56, 56), "bhwc", "u8", True),
     ]
     for i, (name, res, s_hw, t_hw, layout, dt, batched) in enumerate(cases):
         g = torch.Generator().manual_seed(100 + i)
@@ -147,11 +154,15 @@ def main():
             src, tgt = src.permute(0, 3, 1, 2).contiguous(), tgt.permute(0, 3, 1, 2).contiguous()
         if not batched:
             src, tgt = src[0], tgt[0]
-        m = FakeModel(res, seed=7 + i)
+        m = FakeModel(res, seed=7 + i, with_cov=name.startswith("cov_"))
         out = m.predict_correspondences_batched(src, tgt, data_norm_type=norm)
         assert out.covisibility.logits is None
+        extra = {}
+        if m.with_cov:
+            extra = dict(cov_in=np_(m.cov_in), cov_out=np_(out.flow.flow_covariance))
         save(
             f"glue_prepost_{name}.npz",
+            **extra,
             src=np_(src),
             tgt=np_(tgt),
             resolutions=np.array(res if isinstance(res, list) else [res]),
@@ -224,6 +235,44 @@ def main():
             out2 = model.predict_correspondences_batched(src2, tgt2)
         arrays.update(src2=np_(src2), tgt2=np_(tgt2), flow2=np_(out2.flow.flow_output), mask2=np_(out2.covisibility.mask))
         save(f"wiring_{name}.npz", **arrays)
+
+    # ----------------------------------------------------------------- UNet
+    # models/unet_encoder.py loads standalone: the reference's OWN class, seeded weights (R.init_weights_), odd sizes that
+    # exercise the nearest fix-up at :66-67 (54 -> 27 -> 13 -> 6; 13 vs 2*6, 27 vs 2*13)
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("ref_unet_encoder", os.path.join(REF, "uniflowmatch", "models", "unet_encoder.py"))
+    ref_unet = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_unet)
+    for name, feats, shape in [("small_odd", [8, 16, 32, 64], (1, 3, 38, 54)), ("small_even", [8, 16, 32, 64], (2, 3, 64, 48)),
+                               ("full_odd", [64, 128, 256, 512], (1, 3, 42, 70))]:
+        net = ref_unet.UNet(in_channels=3, out_channels=16, features=feats).eval()
+        R.init_weights_(net, seed=5)
+        gx = torch.Generator().manual_seed(31)
+        x = torch.randn(shape, generator=gx)
+        with torch.no_grad():
+            y = net(x)
+        save(f"unet_{name}.npz", x=np_(x), y=np_(y), seed=np.array(5), features=np.array(feats),
+             keys=np.array(sorted(net.state_dict().keys())), weight_abs_sum=np.array(float(sum(p.double().abs().sum() for p in net.parameters()))))
+
+    # the reference's real UFM-Refine forward with use_unet_feature=True (ufm.py:816-825, :915-917, :967-983)
+    for method in ("conv", "modulate"):
+        cfg = R.ufm_tiny_config(refine=True, use_unet_feature=True, feature_combine_method=method)
+        kw = dict(cfg)
+        kw["classification_head_type"] = "patch_mlp"
+        model = ref_ufm.UniFlowMatchClassificationRefinement(**kw).eval()
+        R.init_weights_(model, seed=3)
+        g = torch.Generator().manual_seed(23)
+        src = torch.randint(0, 256, (2, 56, 56, 3), dtype=torch.uint8, generator=g)
+        tgt = torch.randint(0, 256, (2, 56, 56, 3), dtype=torch.uint8, generator=g)
+        with torch.no_grad():
+            out = model.predict_correspondences_batched(src, tgt)
+            s_n, t_n = R.to_bchw_normalised(src, tgt, "dinov2", None)
+            low = model(dict(img=s_n, symmetrized=False, data_norm_type="dinov2"), dict(img=t_n, symmetrized=False, data_norm_type="dinov2"))
+        wsum = float(sum(p.double().abs().sum() for p in model.parameters()))
+        save(f"wiring_refine_unet_{method}.npz", src=np_(src), tgt=np_(tgt), seed=np.array(3), weight_abs_sum=np.array(wsum),
+             flow=np_(out.flow.flow_output), mask=np_(out.covisibility.mask), feature_map_0=np_(low.classification_refinement.feature_map_0),
+             residual=np_(low.classification_refinement.residual), keys=np.array(sorted(model.state_dict().keys())))
 
     # -------------------------------------------------------------- selfdemo
     sel = ref_fr.AutomaticShapeSelection(

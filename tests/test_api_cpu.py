@@ -88,3 +88,76 @@ def test_error_behaviour_without_gpu():
         ufm_amd.UniFlowMatchConfidence(**{**ufm_amd.ufm_tiny_config(), "info_sharing_str": "cross_attention"})
     with pytest.raises(RuntimeError, match="parameter container"):
         m.encoder(None)
+
+
+def test_checkpoint_loading_is_never_silent(tmp_path):
+    """PyTorchModelHubMixin's default load is strict=False with no check -- a parameter whose key differs would
+    keep its random init and `ufm infer --weights` would write plausible but wrong images.  ufm_amd routes every loader
+    through keymap.load_checked: missing parameters raise (ufm.py:216-217), extra keys must be on the allow list."""
+    from safetensors.torch import load_file, save_file
+
+    from ufm_amd import keymap
+
+    m = ufm_amd.UniFlowMatchConfidence(**ufm_amd.ufm_tiny_config())
+    ufm_amd.modules.init_weights_(m, 2)
+    d = tmp_path / "good"
+    m.save_pretrained(str(d))
+    sd = load_file(str(d / "model.safetensors"))
+
+    def variant(name, edit):
+        v = tmp_path / name
+        v.mkdir()
+        (v / "config.json").write_text((d / "config.json").read_text())
+        s2 = dict(sd)
+        edit(s2)
+        save_file(s2, str(v / "model.safetensors"))
+        return str(v)
+
+    # a renamed key = one missing + one unexpected: must raise and name both
+    def rename(s2):
+        s2["encoder.model.pos_embedding"] = s2.pop("encoder.model.pos_embed")
+    with pytest.raises(RuntimeError, match="pos_embed"):
+        ufm_amd.UniFlowMatchConfidence.from_pretrained(variant("renamed", rename))
+    # a deleted key must raise
+    with pytest.raises(RuntimeError, match="missing from the file"):
+        ufm_amd.UniFlowMatchConfidence.from_pretrained(variant("deleted", lambda s2: s2.pop("head1.0.1.conv1.weight")))
+    # allowed extras (the DINOv2 mask token the reference drops, ufm.py:209) load fine and leave every parameter exact
+    ok = ufm_amd.UniFlowMatchConfidence.from_pretrained(variant("extra", lambda s2: s2.update({"encoder.model.mask_token": torch.zeros(1, 128)})))
+    for (k1, v1), (k2, v2) in zip(sorted(m.state_dict().items()), sorted(ok.state_dict().items())):
+        assert k1 == k2 and torch.equal(v1, v2)
+    # an unknown extra key is an error too (it usually means a renamed parameter)
+    with pytest.raises(RuntimeError, match="does not have"):
+        ufm_amd.UniFlowMatchConfidence.from_pretrained(variant("junk", lambda s2: s2.update({"encoder.model.something_new": torch.zeros(1)})))
+
+    # Lightning-style training checkpoint through pretrained_checkpoint_path (ufm.py:198-211): "model." prefix, dropped keys
+    ck = {"state_dict": {**{"model." + k: v for k, v in sd.items() if not k.startswith("uncertainty_head")},
+                         "model.feature_matching_proj.weight": torch.zeros(2, 2), "model.encoder.model.mask_token": torch.zeros(1, 128),
+                         "loss.weight": torch.zeros(1)}}
+    path = str(tmp_path / "train.ckpt")
+    torch.save(ck, path)
+    cfg = ufm_amd.ufm_tiny_config()
+    base = ufm_amd.UniFlowMatch(encoder_str=cfg["encoder_str"], encoder_kwargs=cfg["encoder_kwargs"], info_sharing_kwargs=cfg["info_sharing_kwargs"],
+                                feature_head_kwargs=cfg["feature_head_kwargs"], adaptors_kwargs=cfg["adaptors_kwargs"], pretrained_checkpoint_path=path)
+    assert torch.equal(base.state_dict()["encoder.model.pos_embed"], sd["encoder.model.pos_embed"])
+    ck["state_dict"].pop("model.info_sharing.self_attention_blocks.0.attn.qkv.weight")
+    torch.save(ck, path)
+    with pytest.raises(RuntimeError, match="info_sharing.self_attention_blocks.0.attn.qkv.weight"):
+        ufm_amd.UniFlowMatch(encoder_str=cfg["encoder_str"], encoder_kwargs=cfg["encoder_kwargs"], info_sharing_kwargs=cfg["info_sharing_kwargs"],
+                             feature_head_kwargs=cfg["feature_head_kwargs"], adaptors_kwargs=cfg["adaptors_kwargs"], pretrained_checkpoint_path=path)
+    assert keymap.normalise({"model.a.b": 1, "other": 2}, lightning=True) == {"a.b": 1}
+
+
+def test_uncertainty_head_with_covariance_and_keypoint_confidence_constructs():
+    """(f)3: the optional uncertainty-head branches of ufm.py:648-654 are part of the head's adaptor map."""
+    cfg = ufm_amd.ufm_tiny_config()
+    cfg["uncertainty_head_kwargs"]["dpt_processor"]["output_dim"] = 5
+    cfg["uncertainty_adaptors_kwargs"] = dict(
+        non_occluded_mask={"class": "MaskAdaptor", "kwargs": dict(name="non_occluded_mask")},
+        flow_cov={"class": "Covariance2DAdaptor", "kwargs": dict(name="flow_cov")},
+        keypoint_confidence={"class": "ConfidenceAdaptor", "kwargs": dict(name="keypoint_confidence", confidence_type="sigmoid", vmin=0.0, vmax=1.0)},
+    )
+    m = ufm_amd.UniFlowMatchConfidence(**cfg)
+    ad = m.uncertainty_head[1].adaptors
+    assert [a.required_channels for a in ad] == [1, 3, 1] and m.uncertainty_head[0][1].output_dim == 5
+    with pytest.raises(ValueError, match="adaptors need"):
+        ufm_amd.UniFlowMatchConfidence(**{**cfg, "uncertainty_head_kwargs": {**cfg["uncertainty_head_kwargs"], "dpt_processor": dict(input_feature_dim=64, output_dim=4)}})

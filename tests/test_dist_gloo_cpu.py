@@ -29,6 +29,23 @@ def _worker(rank, world, port, n_pairs, ret):
     flow, mask = predict_sharded(_fake_predict, src, tgt)
     ref_flow, ref_mask = _fake_predict(src, tgt)
     ok = torch.equal(flow, ref_flow) and torch.equal(mask, ref_mask)
+    # the asynchronous double-buffered form bench.py runs: three steps in flight over a ring of two slots
+    from ufm_amd.dist import ShardedPredictor
+
+    sp = ShardedPredictor(_fake_predict, depth=2)
+    tickets, batches = [], []
+    for step in range(3):
+        s2, t2 = src.roll(step, 0), tgt.roll(step, 0)
+        batches.append((s2, t2))
+        tickets.append(sp.submit(s2, t2))
+        if step >= 1:  # consume the previous step while this one's gather is in flight
+            f, m = sp.result(tickets[step - 1])
+            rf, rm = _fake_predict(*batches[step - 1])
+            ok = ok and torch.equal(f, rf) and torch.equal(m, rm)
+    f, m = sp.result(tickets[-1])
+    rf, rm = _fake_predict(*batches[-1])
+    ok = ok and torch.equal(f, rf) and torch.equal(m, rm)
+    sp.drain()
     lo, hi = shard_bounds(n_pairs, rank, world)
     ret[rank] = (ok, lo, hi)
     dist.destroy_process_group()
@@ -40,7 +57,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,n_pairs", [(2, 8), (3, 7), (2, 1)])
+@pytest.mark.parametrize("world,n_pairs", [(2, 8), (3, 7), (2, 1), (3, 2)])  # (2,1), (3,2): ranks with an EMPTY shard still join the gather
 def test_sharded_predict_matches_unsharded(world, n_pairs):
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
@@ -62,7 +79,7 @@ def test_sharded_predict_matches_unsharded(world, n_pairs):
 def test_shard_bounds_properties():
     from ufm_amd.dist import shard_bounds
 
-    for n in (1, 7, 8, 64):
+    for n in (1, 2, 7, 8, 64):
         for w in (1, 2, 3, 8):
             b = [shard_bounds(n, r, w) for r in range(w)]
             assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))

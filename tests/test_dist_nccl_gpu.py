@@ -1,0 +1,28 @@
+"""The N > 1 path on the real backend (SURVEY 8(e) "tooling caveat"): ``torch.distributed.run`` with one process per
+visible GPU (1 on the lease box, 8 when the driver has a node) as a fresh CHILD process -- never an exec of the test
+process -- running tests/_dist_nccl_worker.py, which asserts gathered == unsharded bitwise on backend "nccl" (RCCL)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_predict_sharded_on_rccl_equals_unsharded():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    n = min(torch.cuda.device_count(), 6)  # at most 6 processes may use the card(s) at once on the lease boxes
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "_dist_nccl_worker.py")]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert f"DIST-NCCL-OK world={n}" in r.stdout

@@ -115,7 +115,17 @@ def test_tiny_fast_mode_tolerance(env):
     p = prod.set_numerics("fast").predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
     df, dm, mx = compare(o, p)
     print(f"fast-mode tiny: flow max-abs {df:.4g} (range {mx:.3g}), mask max-abs {dm:.4g}")
-    assert df <= 0.05 * mx and dm <= 0.05, (df, dm, mx)  # bf16 trunk: a few % of range at random O(1) weights
+    # bf16 trunk at random O(1) weights: measured 0.017 px on a range of 2.6 (0.65 %), mask 4e-3; bound = 2x measured
+    assert df <= 0.013 * mx and dm <= 0.01, (df, dm, mx)
+    # ... and it is the REFERENCE's own bf16 policy that moves the outputs that far: the oracle under bf16 autocast
+    # (trunk bf16, heads fp32: base.py:273, ufm.py:635) is as far from the fp32 oracle as the fast mode is
+    oracle.autocast_bf16 = True
+    oa = oracle.predict_correspondences_batched(src, tgt)
+    oracle.autocast_bf16 = False
+    e_ac = (oa.flow.flow_output - o.flow.flow_output).abs()
+    e_fast_ac = (p.flow.flow_output.cpu() - oa.flow.flow_output).abs()
+    print(f"tiny: autocast-oracle vs fp32 oracle max {e_ac.max():.4g} mean {e_ac.mean():.4g}; fast vs autocast-oracle max {e_fast_ac.max():.4g} mean {e_fast_ac.mean():.4g}")
+    assert e_fast_ac.mean().item() <= 1.5 * e_ac.mean().item() + 1e-4 and e_fast_ac.max().item() <= 1.5 * e_ac.max().item() + 1e-3
 
 
 def test_forward_lower_level_api_and_errors(env):
@@ -171,11 +181,28 @@ def test_ufm_base_full_size_parity(env):
     df, dm, mx = compare(o, p)
     print(f"UFM-Base 518 parity mode: flow max-abs {df:.3g} px (range {mx:.3g}), mask {dm:.3g}")
     assert df <= 1e-3 and dm <= 1e-3, (df, dm, mx)
+    # the ONE precision choice of "fast" that is narrower than the reference's fp32 head island (ufm.py:635), isolated:
+    # exact-fp32 trunk + bf16x3 split-precision heads must still meet the 1e-3 px gate
+    px = prod.set_numerics("parity_x3heads").predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
+    dfx, dmx, _ = compare(o, px)
+    print(f"UFM-Base 518 fp32 trunk + bf16x3 heads: flow max-abs {dfx:.3g} px, mask {dmx:.3g}")
+    assert dfx <= 1e-3 and dmx <= 1e-3, (dfx, dmx, mx)
     pf = prod.set_numerics("fast").predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
     df2, dm2, _ = compare(o, pf)
     mean_abs = (o.flow.flow_output - pf.flow.flow_output.cpu()).abs().mean().item()
     print(f"UFM-Base 518 fast (bf16) mode: flow max-abs {df2:.3g} mean-abs {mean_abs:.3g} (range {mx:.3g}), mask {dm2:.3g}")
-    assert df2 <= 0.05 * mx and dm2 <= 0.05, (df2, dm2, mx)
+    # measured: flow max-abs 0.037 px / mean-abs 0.006 on a range of 3.6 (1 %), mask 5.9e-3; bound = 2x measured
+    assert df2 <= 0.021 * mx and mean_abs <= 0.012 and dm2 <= 0.012, (df2, mean_abs, dm2, mx)
+    # the reference's own GPU policy (bf16 autocast trunk, fp32 heads) moves the outputs just as far: the fast mode
+    # stays within 1.5x of the autocast oracle's own distance from the fp32 oracle
+    oracle.autocast_bf16 = True
+    oa = oracle.predict_correspondences_batched(src, tgt)
+    oracle.autocast_bf16 = False
+    e_ac = (oa.flow.flow_output - o.flow.flow_output).abs()
+    e_fast_ac = (pf.flow.flow_output.cpu() - oa.flow.flow_output).abs()
+    print(f"UFM-Base 518: autocast-oracle vs fp32 oracle max {e_ac.max():.3g} mean {e_ac.mean():.3g}; fast vs autocast-oracle max {e_fast_ac.max():.3g} mean {e_fast_ac.mean():.3g}; fast vs fp32 oracle max {df2:.3g} mean {mean_abs:.3g}")
+    assert mean_abs <= 1.5 * e_ac.mean().item() and df2 <= 1.5 * e_ac.max().item(), (mean_abs, df2, e_ac.mean().item(), e_ac.max().item())
+    assert e_fast_ac.mean().item() <= 1.5 * e_ac.mean().item() and e_fast_ac.max().item() <= 1.5 * e_ac.max().item()
 
 
 def test_config4_ufm_refine_full_size_parity(env):
@@ -227,7 +254,7 @@ def test_config5_1036_long_sequence_properties(env):
     d = (par.flow.flow_output - f1[:1]).abs().max().item()
     dm = (par.covisibility.mask - fast.covisibility.mask[:1]).abs().max().item()
     print(f"1036x1036: fast-vs-parity flow max-abs {d:.3g} (range {rng:.3g}), mask {dm:.3g}")
-    assert d <= 0.05 * rng and dm <= 0.05
+    assert d <= 0.025 * rng and dm <= 0.02  # measured 0.040 px on a range of 3.5 (1.1 %), mask 7e-3; bound = 2x measured
 
 
 def test_config1_shapes_unequal_sizes_multi_resolution(env):
@@ -340,3 +367,97 @@ def test_full_size_batch_shards_are_bitwise_equal_across_kernel_dispatch(env):
         assert torch.equal(one.covisibility.mask[0], wm[i]), i
     again = model.predict_correspondences_batched(src, tgt)
     assert torch.equal(again.flow.flow_output, wf) and torch.equal(again.covisibility.mask, wm)
+
+
+def test_hip_graph_replay_is_bitwise_eager(env):
+    """ufm_amd.GraphedPredictor: one predict_correspondences_batched captured into a HIP graph (the C ABI never allocates
+    or synchronises); replays on new inputs must equal the eager call bit for bit -- tiny model incl. a non-identity
+    resolution (antialias resize kernels in the graph) and UFM-Refine (refinement kernels in the graph)."""
+    ufm_amd, R = env
+    for refine, shape in ((False, (1, 56, 56, 3)), (False, (2, 70, 90, 3)), (True, (1, 56, 56, 3))):
+        _, prod = build_pair(env, refine=refine)
+        prod.set_numerics("fast")
+        a, b = u8(shape, 11).to(DEV), u8(shape, 12).to(DEV)
+        gp = ufm_amd.GraphedPredictor(prod, a, b)
+        for seed in (21, 22):
+            s, t = u8(shape, seed).to(DEV), u8(shape, seed + 100).to(DEV)
+            want = prod.predict_correspondences_batched(s, t)
+            wf, wm = want.flow.flow_output.clone(), want.covisibility.mask.clone()
+            got = gp(s, t)
+            assert torch.equal(got.flow.flow_output, wf) and torch.equal(got.covisibility.mask, wm), (refine, shape, seed)
+        with pytest.raises(ValueError, match="different input signature"):
+            gp(torch.zeros(3, 56, 56, 3, dtype=torch.uint8, device=DEV), torch.zeros(3, 56, 56, 3, dtype=torch.uint8, device=DEV))
+
+
+def _cov_conf_config(mod):
+    """Tiny model whose uncertainty head carries all three named outputs of ufm.py:644-660."""
+    cfg = mod.ufm_tiny_config()
+    cfg["uncertainty_head_kwargs"]["dpt_processor"]["output_dim"] = 5
+    cfg["uncertainty_adaptors_kwargs"] = dict(
+        non_occluded_mask={"class": "MaskAdaptor", "kwargs": dict(name="non_occluded_mask")},
+        flow_cov={"class": "Covariance2DAdaptor", "kwargs": dict(name="flow_cov")},
+        keypoint_confidence={"class": "ConfidenceAdaptor", "kwargs": dict(name="keypoint_confidence", confidence_type="sigmoid", vmin=0.0, vmax=1.0)},
+    )
+    return cfg
+
+
+@pytest.mark.parametrize("numerics", ["parity", "fast"])
+def test_covariance_and_keypoint_confidence_outputs_vs_oracle(env, numerics):
+    """(f)3: Covariance2DAdaptor / ConfidenceAdaptor branches of the uncertainty head (ufm.py:648-654) and the covariance
+    un-mapping with the [wr^2, hr^2, wr*hr] rescale (base.py:295-319), on resized inputs.  The adaptor formulas are the
+    oracle's restatement of the absent uniception classes (parity unpinned); the un-map rescale is pinned separately by
+    the reference-generated golden below."""
+    oracle, prod = build_pair(env, cfg_fn=_cov_conf_config)
+    prod.set_numerics(numerics)
+    src, tgt = u8((2, 75, 100, 3), 5), u8((2, 60, 90, 3), 6)
+    o = oracle.predict_correspondences_batched(src, tgt)
+    p = prod.predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
+    tol = 1.5e-3 if numerics == "parity" else 0.02
+    assert (o.flow.flow_output - p.flow.flow_output.cpu()).abs().max() <= (tol if numerics == "parity" else 0.02 * o.flow.flow_output.abs().max())
+    cov_o, cov_p = o.flow.flow_covariance, p.flow.flow_covariance.cpu()
+    assert cov_p.shape == (2, 3, 75, 100) == cov_o.shape
+    rel = ((cov_o - cov_p).abs() / (cov_o.abs() + 1e-3)).max().item()
+    assert rel <= (2e-3 if numerics == "parity" else 0.1), rel  # covariance = exp(2 * logit): relative error = 2 x logit error
+    assert (o.covisibility.mask - p.covisibility.mask.cpu()).abs().max() <= (1e-3 if numerics == "parity" else 0.02)
+    # network-resolution outputs of forward(): inverse covariance, log-determinant, keypoint confidence
+    a, b = torch.randn(1, 3, 56, 56, generator=torch.Generator().manual_seed(3)), torch.randn(1, 3, 56, 56, generator=torch.Generator().manual_seed(4))
+    fo = oracle.forward(a, b)
+    v = lambda t: {"img": t.to(DEV), "symmetrized": False, "data_norm_type": "dinov2"}  # noqa: E731
+    fp = prod(v(a), v(b))
+    assert fp.keypoint_confidence.shape == (1, 56, 56) and fp.flow.flow_covariance_log_det.shape == (1, 1, 56, 56)
+    t2 = 2e-3 if numerics == "parity" else 0.1
+    assert (fo.keypoint_confidence - fp.keypoint_confidence.cpu()).abs().max() <= t2
+    assert (fo.flow.flow_covariance_log_det - fp.flow.flow_covariance_log_det.cpu()).abs().max() <= 2 * t2
+    inv_o, inv_p = fo.flow.flow_covariance_inv, fp.flow.flow_covariance_inv.cpu()
+    assert ((inv_o - inv_p).abs() / (inv_o.abs() + 1e-3)).max() <= 2 * t2
+    # cov . inv_cov = I per pixel (property of the kernel's own outputs)
+    c, i = fp.flow.flow_covariance.cpu().double(), fp.flow.flow_covariance_inv.cpu().double()
+    assert (c[:, 0] * i[:, 0] + c[:, 2] * i[:, 2] - 1).abs().max() <= 1e-3 and (c[:, 0] * i[:, 2] + c[:, 2] * i[:, 1]).abs().max() <= 1e-3
+
+
+@pytest.mark.parametrize("name", ["glue_prepost_cov_down_u8.npz", "glue_prepost_cov_ident_u8.npz"])
+def test_covariance_unmap_against_reference_golden(env, golden_dir, name):
+    """Pinned: the reference's own _predict_correspondences_batched (base.py:236-334) around a fake forward that returns a
+    flow_covariance (tests/golden/make_goldens.py); the product's pre/post-processing kernels around the same fields."""
+    ufm_amd, R = env
+    from tests.golden.make_goldens import analytic_fields
+
+    g = np.load(os.path.join(golden_dir, name))
+    _, prod = build_pair(env)
+    prod.inference_resolution = [tuple(int(v) for v in r) for r in g["resolutions"]]
+    cov_in = torch.from_numpy(g["cov_in"]).to(DEV)
+
+    def fake_forward_device(src, tgt, layout, scale3, shift3, H, W, hs, ws, ht, wt):
+        fl, mask = analytic_fields(src.shape[0], H, W, int(g["fake_seed"]))
+        out = ufm_amd.UFMOutputInterface()
+        out.flow = ufm_amd.UFMFlowFieldOutput(flow_output=fl.to(DEV), flow_covariance=cov_in)
+        out.covisibility = ufm_amd.UFMMaskFieldOutput(mask=mask.to(DEV), logits=None)
+        return out
+
+    prod._forward_device = fake_forward_device
+    p = prod.predict_correspondences_batched(torch.from_numpy(g["src"]).to(DEV), torch.from_numpy(g["tgt"]).to(DEV))
+    assert np.abs(p.flow.flow_output.cpu().numpy() - g["flow"]).max() <= 1e-4
+    assert np.abs(p.covisibility.mask.cpu().numpy() - g["mask"]).max() <= 1e-5
+    cov = p.flow.flow_covariance.cpu().numpy()
+    assert cov.shape == g["cov_out"].shape
+    assert np.abs(cov - g["cov_out"]).max() <= 1e-5 * max(1.0, float(np.abs(g["cov_out"]).max()))

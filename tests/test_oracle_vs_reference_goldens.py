@@ -29,13 +29,17 @@ class _FakeOracle(R.UFMRef):
         self.encoder = SimpleNamespace(data_norm_type="dinov2")
         self.seed = seed
         self.seen = None
+        self.cov_in = None
 
     def forward(self, a, b):
         from tests.golden.make_goldens import analytic_fields
 
         self.seen = (a.clone(), b.clone())
         fl, mask = analytic_fields(a.shape[0], a.shape[2], a.shape[3], self.seed)
-        return R.Out(flow=R.FlowOut(fl), covisibility=R.MaskOut(mask, mask * 0))
+        out = R.Out(flow=R.FlowOut(fl), covisibility=R.MaskOut(mask, mask * 0))
+        if self.cov_in is not None:  # the generator's FakeModel returned this flow_covariance (base.py:295-319 branch)
+            out.flow.flow_covariance = self.cov_in
+        return out
 
 
 @pytest.mark.parametrize(
@@ -46,6 +50,8 @@ def test_prepost_glue(golden_dir, name):
     res = [tuple(int(v) for v in r) for r in g["resolutions"]]
     norm = str(g["norm"]) or None
     m = _FakeOracle(res, int(g["fake_seed"]))
+    if "cov_in" in g:
+        m.cov_in = torch.from_numpy(g["cov_in"])
     out = m.predict_correspondences_batched(torch.from_numpy(g["src"]), torch.from_numpy(g["tgt"]), data_norm_type=norm)
     assert m.seen[0].shape == g["seen1"].shape
     assert np.abs(m.seen[0].numpy() - g["seen1"]).max() <= TOL
@@ -55,6 +61,9 @@ def test_prepost_glue(golden_dir, name):
     assert out.covisibility.mask.shape == g["mask"].shape
     assert np.abs(out.covisibility.mask.numpy() - g["mask"]).max() <= TOL
     assert out.covisibility.logits is None
+    if "cov_out" in g:
+        assert out.flow.flow_covariance.shape == g["cov_out"].shape
+        assert np.abs(out.flow.flow_covariance.numpy() - g["cov_out"]).max() <= TOL * max(1.0, float(np.abs(g["cov_out"]).max()))
 
 
 @pytest.mark.parametrize("name", ["unmap_full.npz", "unmap_crop.npz"])
@@ -123,3 +132,37 @@ def test_known_answer_identity():
     assert (fo - fl).abs().max() <= 3.1e-5
     co, _ = R.unmap_channels(fl, p0, s0, (70, 70))
     assert torch.equal(co, fl)
+
+
+@pytest.mark.parametrize("name", ["unet_small_odd.npz", "unet_small_even.npz", "unet_full_odd.npz"])
+def test_unet_restatement_is_pinned(golden_dir, name):
+    """R5: oracle UNetRef vs the reference's own UNet (models/unet_encoder.py loads standalone; the generator seeds the
+    reference class with init_weights_(seed), the same call re-creates identical weights here): same state-dict keys,
+    same outputs, odd sizes exercising the nearest fix-up of unet_encoder.py:66-67."""
+    g = _load(golden_dir, name)
+    net = R.UNetRef(in_channels=3, out_channels=16, features=[int(f) for f in g["features"]]).eval()
+    R.init_weights_(net, seed=int(g["seed"]))
+    assert sorted(net.state_dict().keys()) == [str(k) for k in g["keys"]]
+    wsum = float(sum(p.double().abs().sum() for p in net.parameters()))
+    assert abs(wsum - float(g["weight_abs_sum"])) <= 1e-6 * wsum
+    with torch.no_grad():
+        y = net(torch.from_numpy(g["x"]))
+    assert y.shape == g["y"].shape
+    assert np.abs(y.numpy() - g["y"]).max() <= 2e-5 * max(1.0, float(np.abs(g["y"]).max()))
+
+
+@pytest.mark.parametrize("method", ["conv", "modulate"])
+def test_refine_with_unet_wiring_is_pinned(golden_dir, method):
+    """The reference's real UFM-Refine forward with use_unet_feature=True (ufm.py:816-825, :915-917, :967-983) running on
+    the restated third-party blocks: which tensors are concatenated / modulated, conv1 -> ReLU -> conv2, chunk order."""
+    g = _load(golden_dir, f"wiring_refine_unet_{method}.npz")
+    m = R.UFMRef(**R.ufm_tiny_config(refine=True, use_unet_feature=True, feature_combine_method=method)).eval()
+    R.init_weights_(m, seed=int(g["seed"]))
+    assert sorted(m.state_dict().keys()) == [str(k) for k in g["keys"]]
+    out = m.predict_correspondences_batched(torch.from_numpy(g["src"]), torch.from_numpy(g["tgt"]))
+    assert np.abs(out.flow.flow_output.numpy() - g["flow"]).max() <= 2e-4
+    assert np.abs(out.covisibility.mask.numpy() - g["mask"]).max() <= 1e-5
+    s_n, t_n = R.to_bchw_normalised(torch.from_numpy(g["src"]), torch.from_numpy(g["tgt"]), "dinov2", None)
+    low = m.forward(s_n, t_n)
+    assert np.abs(low.classification_refinement.feature_map_0.numpy() - g["feature_map_0"]).max() <= 1e-4 * max(1.0, float(np.abs(g["feature_map_0"]).max()))
+    assert np.abs(low.classification_refinement.residual.numpy() - g["residual"]).max() <= 2e-4

@@ -3,10 +3,25 @@
 per-launch HBM bytes (FETCH_SIZE is in KiB and is doubled: on gfx950 it reports exactly half the bytes of wide
 coalesced reads -- MI355X_MICROARCH.md section HBM; WRITE_SIZE is exact for 16-B stores), MFMA-busy fraction, LDS
 bank-conflict cycles."""
-import collections, csv, glob, json, sys
-out_path = sys.argv[1] if len(sys.argv) > 1 else "profiles/r01/pmc_step_summary.json"
+import collections, csv, glob, hashlib, json, os, subprocess, sys
+out_path = sys.argv[1] if len(sys.argv) > 1 else "profiles/r02/pmc_step_summary.json"
+
+
+def csrc_sha256(root):
+    """Content hash of the kernel sources the counters were measured on (bench.py recomputes it: a summary whose hash
+    differs from the tree it runs in is stale and its `traffic` is dropped)."""
+    h = hashlib.sha256()
+    d = os.path.join(root, "ufm_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STEPS = 3  # tools/pmc_traffic.sh traces --warmup 1 --steps 2: three identical steps
-FAM = {"gemm_bf16": "ufm_gemm_bf16", "attn_bf16_kernel": "ufm_attention_bf16", "conv_x3": "ufm_conv2d_nhwc_bf16x3",
+FAM = {"gemm_bf16": "ufm_gemm_bf16", "attn_bf16_kernel": "ufm_attention_bf16", "attn_pw_kernel": "ufm_attention_bf16", "conv_x3": "ufm_conv2d_nhwc_bf16x3",
        "layernorm_kernel": "ufm_layernorm", "upsample": "ufm_upsample_bilinear_nhwc", "dpt_tail_fused": "ufm_dpt_tail_fused", "head_tail_kernel": "ufm_head_tail",
        "patchify": "ufm_patchify", "unmap": "ufm_unmap", "conv_f32": "ufm_conv2d_nhwc_f32"}
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -35,6 +50,14 @@ for fam, d in acc.items():
         e["wave_wait_frac"] = a["SQ_WAIT_ANY"] / a["SQ_WAVE_CYCLES"]
         e["lds_bank_conflict_cycles"] = a["SQ_LDS_BANK_CONFLICT"]
     res[fam] = e
+try:
+    commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
+except Exception:
+    commit = ""
+res["_meta"] = {"csrc_sha256": csrc_sha256(ROOT), "commit_at_summarise_time": commit,
+                "command": "tools/pmc_traffic.sh (bench.py --steps 2 --warmup 1 --micro-batches 1, separate --pmc passes)"}
 json.dump(res, open(out_path, "w"), indent=1)
 for k, v in res.items():
+    if k == "_meta":
+        continue
     print(k, {a: (round(b, 3) if isinstance(b, float) and b < 10 else int(b)) for a, b in v.items()})

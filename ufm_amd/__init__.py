@@ -14,6 +14,7 @@ from .base import (
     UniFlowMatchModelsBase,
 )
 from .configs import make_config, ufm_base_config, ufm_refine_config, ufm_tiny_config
+from .graph import GraphedPredictor
 from .ufm import UniFlowMatch, UniFlowMatchClassificationRefinement, UniFlowMatchConfidence
 
 __all__ = [
@@ -25,6 +26,7 @@ __all__ = [
     "UniFlowMatch",
     "UniFlowMatchClassificationRefinement",
     "UniFlowMatchConfidence",
+    "GraphedPredictor",
     "make_config",
     "ufm_base_config",
     "ufm_refine_config",

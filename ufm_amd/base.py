@@ -81,9 +81,11 @@ class UniFlowMatchModelsBase(torch.nn.Module):
 
     # --- engine plumbing -------------------------------------------------------------------
     def set_numerics(self, numerics: str) -> "UniFlowMatchModelsBase":
-        """"fast": bf16 MFMA trunk (the reference's GPU autocast policy); "parity": fp32 MFMA everywhere."""
-        if numerics not in ("fast", "parity"):
-            raise ValueError("numerics must be 'fast' or 'parity'")
+        """"fast": bf16 MFMA trunk (the reference's GPU autocast policy) + bf16x3 split-precision heads;
+        "parity": fp32 MFMA everywhere; "parity_x3heads": fp32 MFMA trunk + the bf16x3 heads of "fast"
+        (isolates the one choice of "fast" that is narrower than the reference's fp32 head island, ufm.py:635)."""
+        if numerics not in ("fast", "parity", "parity_x3heads"):
+            raise ValueError("numerics must be 'fast', 'parity' or 'parity_x3heads'")
         if numerics != self.numerics:
             self.numerics, self._engine = numerics, None
         return self
@@ -169,6 +171,12 @@ class UniFlowMatchModelsBase(torch.nn.Module):
             flow_un = torch.empty((B, 2, hs, ws), device=src.device, dtype=torch.float32)
             hip.unmap_flow(flow, B, H, W, reg0_rep, reg0_src, reg1_src, hs, ws, flow_un)
             out.flow = UFMFlowFieldOutput(flow_output=flow_un)
+            if res.flow.flow_covariance is not None:  # base.py:295-319: un-map, then [wr^2, hr^2, wr*hr]
+                cov = res.flow.flow_covariance.contiguous()
+                cov_un = torch.empty((B, 3, hs, ws), device=src.device, dtype=torch.float32)
+                wr, hr = ws / W, hs / H
+                hip.unmap_channels(cov, B, 3, H, W, reg0_rep, reg0_src, hs, ws, cov_un, chan_scale=[wr**2, hr**2, wr * hr])
+                out.flow.flow_covariance = cov_un
             if res.covisibility is not None:
                 m = res.covisibility.mask.contiguous()
                 m_un = torch.empty((B, 1, hs, ws), device=src.device, dtype=torch.float32)

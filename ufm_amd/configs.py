@@ -25,6 +25,8 @@ def make_config(
     refine_dim: int = 16,
     refine_mlp_ratio: float = 1.0,
     enc_init_values: Optional[float] = 1.0,
+    use_unet_feature: bool = False,
+    feature_combine_method: str = "conv",
 ) -> Dict[str, Any]:
     dpt_feature = dict(
         patch_size=14,
@@ -58,6 +60,9 @@ def make_config(
         )
         cfg["temperature"] = 4.0
         cfg["refinement_range"] = 5
+        if use_unet_feature:  # ufm.py:816-825: UNet fine features combined with the patch-MLP features
+            cfg["use_unet_feature"] = True
+            cfg["feature_combine_method"] = feature_combine_method
     return cfg
 
 
@@ -66,14 +71,15 @@ def ufm_base_config(resolution_wh: Tuple[int, int] = (518, 518)) -> Dict[str, An
     return make_config(resolution_wh=resolution_wh)
 
 
-def ufm_refine_config(resolution_wh: Tuple[int, int] = (518, 518)) -> Dict[str, Any]:
+def ufm_refine_config(resolution_wh: Tuple[int, int] = (518, 518), **kw: Any) -> Dict[str, Any]:
     """UniFlowMatchClassificationRefinement kwargs (first + last encoder features returned)."""
-    return make_config(resolution_wh=resolution_wh, refine=True, enc_indices=[5, 23])
+    return make_config(resolution_wh=resolution_wh, refine=True, enc_indices=[5, 23], **kw)
 
 
-def ufm_tiny_config(resolution_wh: Tuple[int, int] = (56, 56), refine: bool = False) -> Dict[str, Any]:
+def ufm_tiny_config(resolution_wh: Tuple[int, int] = (56, 56), refine: bool = False, **kw: Any) -> Dict[str, Any]:
     """Same topology at test size; every channel count satisfies the kernels' tile multiples."""
     return make_config(
+        **kw,
         enc_dim=128, enc_depth=3, enc_heads=2, info_dim=128, info_depth=4, info_heads=2, layer_dims=(32, 32, 64, 64),
         feature_dim=64, resolution_wh=resolution_wh, native_img_size=56, refine=refine, enc_indices=[0, 2] if refine else None,
     )

@@ -1,7 +1,7 @@
 // Fused full-resolution tail of the DPT regression processor ("fast" numerics):
 //     bilinear(align_corners) h x w -> H x W   ([U] DPTRegressionProcessor: interpolate to the target size)
 //  -> conv 3x3 pad 1, 128 -> 32, bias, ReLU      (conv2[0], conv2[1])
-//  -> conv 1x1, 32 -> Ct <= 4, bias              (conv2[2])
+//  -> conv 1x1, 32 -> Ct <= 8, bias              (conv2[2])
 //  -> FlowAdaptor / MaskAdaptor                  (models/ufm.py:644-660)
 // in ONE kernel.  Unfused (ufm_upsample_bilinear_nhwc -> ufm_conv2d_nhwc_bf16x3 -> ufm_head_tail) the 128-channel
 // full-resolution map is written once (1.1 GB at B = 8, 518^2) and re-read 9x by the implicit GEMM's tap gathers
@@ -45,8 +45,8 @@ struct TailFusedArgs {
     long long in_plane, w_plane;
     int B, h, w, H, W, Ct;
     float sy, sx;
-    int kind[4];
-    float a[4], d[4];
+    int kind[8];
+    float a[8], d[8];
 };
 
 __device__ __forceinline__ void ld_split8(const uint16_t* hi_ptr, long long plane, float (&v)[8]) {
@@ -59,6 +59,7 @@ __device__ __forceinline__ void ld_split8(const uint16_t* hi_ptr, long long plan
     }
 }
 
+template <int CT>  // compile-time bound on the tail's output channels (4: flow / mask heads; 8: mask + covariance + confidence)
 __global__ __launch_bounds__(256, 2) void dpt_tail_fused_kernel(TailFusedArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[SMEM_B];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -208,12 +209,14 @@ __global__ __launch_bounds__(256, 2) void dpt_tail_fused_kernel(TailFusedArgs p)
         }
     }
     const int oy = ty0 + 4 * wave + (lane >> 4), ox = tx0 + (lane & 15);
-    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    float o[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) o[c] = 0.f;
 #pragma unroll
     for (int k4 = 0; k4 < 8; ++k4) {
         const f32x4 xv = *(const f32x4*)(ws + lane * 128 + ((k4 ^ (lane & 7)) << 4));
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < CT; ++c) {
             if (c < p.Ct) {
                 const f32x4 wv = *(const f32x4*)(p.wt + c * CMID + k4 * 4);
                 o[c] += xv[0] * wv[0];
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void dpt_tail_fused_kernel(TailFusedArgs p)
     if (oy < p.H && ox < p.W) {
         const size_t HW = (size_t)p.H * p.W, q = (size_t)oy * p.W + ox;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < CT; ++c) {
             if (c < p.Ct) {
                 const float y = o[c] + p.bt[c];
                 const size_t oo = ((size_t)b * p.Ct + c) * HW + q;
@@ -249,7 +252,7 @@ extern "C" int ufm_dpt_tail_fused(const uint16_t* in, int B, int h, int w, int C
                                   float* out_logits, void* stream) {
     UFM_REQUIRE(in && w2 && b2 && wt && bt && out && kind_host && a_host && d_host, "ufm_dpt_tail_fused: null pointer");
     UFM_REQUIRE(Cin == CIN && Cmid == CMID, "ufm_dpt_tail_fused: built for 128 -> 32 channels, got %d -> %d", Cin, Cmid);
-    UFM_REQUIRE(B > 0 && h > 1 && w > 1 && H > 1 && W > 1 && Ct >= 1 && Ct <= 4, "ufm_dpt_tail_fused: bad shape");
+    UFM_REQUIRE(B > 0 && h > 1 && w > 1 && H > 1 && W > 1 && Ct >= 1 && Ct <= 8, "ufm_dpt_tail_fused: bad shape");
     UFM_REQUIRE((double)(h - 1) / (H - 1) * (TS + 1) + 2.0 <= TROWS && h <= H && w <= W,
                 "ufm_dpt_tail_fused: built for up-sampling ratios (h-1)/(H-1) <= 0.64 (got %d -> %d)", h, H);
     UFM_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)w2 % 16) == 0 && ((uintptr_t)wt % 16) == 0 && ((uintptr_t)b2 % 16) == 0,
@@ -259,14 +262,15 @@ extern "C" int ufm_dpt_tail_fused(const uint16_t* in, int B, int h, int w, int C
     p.in_plane = (long long)B * h * w * CIN, p.w_plane = (long long)CMID * 9 * CIN;
     p.B = B, p.h = h, p.w = w, p.H = H, p.W = W, p.Ct = Ct;
     p.sy = (float)(h - 1) / (float)(H - 1), p.sx = (float)(w - 1) / (float)(W - 1);  // as ufm_upsample_bilinear_nhwc
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < 8; ++c) {
         p.kind[c] = c < Ct ? kind_host[c] : 0;
         p.a[c] = c < Ct ? a_host[c] : 1.f;
         p.d[c] = c < Ct ? d_host[c] : 0.f;
     }
     const long long tiles = (long long)B * ((H + TS - 1) / TS) * ((W + TS - 1) / TS);
     UFM_REQUIRE(tiles < (1ll << 31), "ufm_dpt_tail_fused: problem too large");
-    hipLaunchKernelGGL(dpt_tail_fused_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, p);
+    if (Ct <= 4) hipLaunchKernelGGL(dpt_tail_fused_kernel<4>, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(dpt_tail_fused_kernel<8>, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, p);
     UFM_CHECK_LAUNCH("ufm_dpt_tail_fused");
     return UFM_OK;
 }

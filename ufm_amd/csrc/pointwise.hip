@@ -236,25 +236,28 @@ __global__ __launch_bounds__(256) void upsample_split_tiled_kernel(const uint16_
     }
 }
 
+constexpr int TAIL_MAX = 8;  // output channels of a head tail (flow 2; mask 1 + covariance 3 + keypoint confidence 1 = 5)
 struct TailArgs {
-    int kind[4];
-    float a[4];
-    float d[4];
+    int kind[TAIL_MAX];
+    float a[TAIL_MAX];
+    float d[TAIL_MAX];
 };
 
 // one thread per pixel; x row is Cin floats (Cin % 4 == 0, <= 64); w/b from global (L1/L2 resident).
-template <int SPLIT>
+template <int SPLIT, int CT>
 __global__ __launch_bounds__(256) void head_tail_kernel(const void* __restrict__ x_, int P, int HW, int Cin,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
                                                         int Cout, TailArgs ta, float* __restrict__ out,
                                                         float* __restrict__ out_logits) {
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        float acc[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = 0.f;
         for (int k = 0; k < Cin; k += 4) {
             const f32x4 xv = SPLIT ? ld_split4((const uint16_t*)x_ + (size_t)p * Cin + k, (size_t)P * Cin)
                                    : *(const f32x4*)((const float*)x_ + (size_t)p * Cin + k);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < CT; ++c) {
                 if (c < Cout) {
                     const f32x4 wv = *(const f32x4*)(w + c * Cin + k);
                     acc[c] += xv[0] * wv[0];
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const void* __restrict__
         }
         const int b = p / HW, q = p - b * HW;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < CT; ++c) {
             if (c < Cout) {
                 const float y = acc[c] + bias[c];
                 const size_t o = ((size_t)b * Cout + c) * HW + q;
@@ -477,19 +480,65 @@ extern "C" int ufm_head_tail(const void* x, int in_dtype, int P, int HW, int Cin
                              const int32_t* kind_host, const float* a_host, const float* d_host, float* out,
                              float* out_logits, void* stream) {
     UFM_REQUIRE(x && w && b && out && kind_host && a_host && d_host, "ufm_head_tail: null pointer");
-    UFM_REQUIRE(Cout >= 1 && Cout <= 4 && Cin % 4 == 0 && Cin > 0 && P > 0 && HW > 0 && P % HW == 0, "ufm_head_tail: bad shape");
+    UFM_REQUIRE(Cout >= 1 && Cout <= TAIL_MAX && Cin % 4 == 0 && Cin > 0 && P > 0 && HW > 0 && P % HW == 0, "ufm_head_tail: bad shape");
     TailArgs ta;
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < TAIL_MAX; ++c) {
         ta.kind[c] = c < Cout ? kind_host[c] : 0;
         ta.a[c] = c < Cout ? a_host[c] : 1.f;
         ta.d[c] = c < Cout ? d_host[c] : 0.f;
     }
     UFM_REQUIRE(in_dtype == UFM_F32 || in_dtype == UFM_BF16X2, "ufm_head_tail: in_dtype must be UFM_F32 or UFM_BF16X2");
-    if (in_dtype == UFM_BF16X2)
-        hipLaunchKernelGGL(head_tail_kernel<1>, stream_grid((size_t)P), dim3(256), 0, (hipStream_t)stream, x, P, HW, Cin, w, b, Cout, ta, out, out_logits);
+    if (in_dtype == UFM_BF16X2 && Cout <= 4)
+        hipLaunchKernelGGL((head_tail_kernel<1, 4>), stream_grid((size_t)P), dim3(256), 0, (hipStream_t)stream, x, P, HW, Cin, w, b, Cout, ta, out, out_logits);
+    else if (in_dtype == UFM_BF16X2)
+        hipLaunchKernelGGL((head_tail_kernel<1, TAIL_MAX>), stream_grid((size_t)P), dim3(256), 0, (hipStream_t)stream, x, P, HW, Cin, w, b, Cout, ta, out, out_logits);
+    else if (Cout <= 4)
+        hipLaunchKernelGGL((head_tail_kernel<0, 4>), stream_grid((size_t)P), dim3(256), 0, (hipStream_t)stream, x, P, HW, Cin, w, b, Cout, ta, out, out_logits);
     else
-        hipLaunchKernelGGL(head_tail_kernel<0>, stream_grid((size_t)P), dim3(256), 0, (hipStream_t)stream, x, P, HW, Cin, w, b, Cout, ta, out, out_logits);
+        hipLaunchKernelGGL((head_tail_kernel<0, TAIL_MAX>), stream_grid((size_t)P), dim3(256), 0, (hipStream_t)stream, x, P, HW, Cin, w, b, Cout, ta, out, out_logits);
     UFM_CHECK_LAUNCH("ufm_head_tail");
+    return UFM_OK;
+}
+
+// ---- output adaptors that are not a per-channel affine / sigmoid ([U] uniception prediction_heads.adaptors;
+// call sites models/ufm.py:648-654).  Inputs are the raw decoded channels (ufm_head_tail kind 0 with a = 1, d = 0). ----
+namespace {
+__global__ __launch_bounds__(256) void covariance2d_kernel(const float* __restrict__ raw, size_t n, size_t HW, float* __restrict__ cov,
+                                                           float* __restrict__ inv, float* __restrict__ logdet) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / HW, q = i - b * HW, o = b * 3 * HW + q;
+        const float sx = expf(raw[o]), sy = expf(raw[o + HW]), rho = tanhf(raw[o + 2 * HW]) * 0.99f;
+        const float cxx = sx * sx, cyy = sy * sy, cxy = rho * sx * sy;
+        const float det = cxx * cyy - cxy * cxy;
+        cov[o] = cxx, cov[o + HW] = cyy, cov[o + 2 * HW] = cxy;
+        inv[o] = cyy / det, inv[o + HW] = cxx / det, inv[o + 2 * HW] = -cxy / det;
+        logdet[b * HW + q] = logf(det);
+    }
+}
+__global__ __launch_bounds__(256) void confidence_kernel(const float* __restrict__ raw, size_t n, int type, float vmin, float vmax,
+                                                         float* __restrict__ out) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float x = raw[i];
+        float v = x;
+        if (type == 0) v = fminf(vmin + expf(x), vmax);
+        else if (type == 1) v = (vmax - vmin) * (1.0f / (1.0f + expf(-x))) + vmin;
+        out[i] = v;
+    }
+}
+}  // namespace
+
+extern "C" int ufm_adaptor_covariance2d(const float* raw, int B, int HW, float* cov, float* inv_cov, float* log_det, void* stream) {
+    UFM_REQUIRE(raw && cov && inv_cov && log_det && B > 0 && HW > 0, "ufm_adaptor_covariance2d: bad args");
+    const size_t n = (size_t)B * HW;
+    hipLaunchKernelGGL(covariance2d_kernel, stream_grid(n), dim3(256), 0, (hipStream_t)stream, raw, n, (size_t)HW, cov, inv_cov, log_det);
+    UFM_CHECK_LAUNCH("ufm_adaptor_covariance2d");
+    return UFM_OK;
+}
+
+extern "C" int ufm_adaptor_confidence(const float* raw, int64_t n, int type, float vmin, float vmax, float* out, void* stream) {
+    UFM_REQUIRE(raw && out && n > 0 && type >= 0 && type <= 2, "ufm_adaptor_confidence: bad args");
+    hipLaunchKernelGGL(confidence_kernel, stream_grid((size_t)n), dim3(256), 0, (hipStream_t)stream, raw, (size_t)n, type, vmin, vmax, out);
+    UFM_CHECK_LAUNCH("ufm_adaptor_confidence");
     return UFM_OK;
 }
 

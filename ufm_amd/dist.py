@@ -5,18 +5,25 @@ Every pair is independent (the reference only ever concatenates / chunks along d
 replicated weights and no data-path collective.  The only exchange is the trivial result gather:
 ONE ``all_gather`` per batch of a packed ``[flow(2) | covisibility(1)]`` fp32 buffer
 (RCCL over xGMI on GPUs: backend "nccl"; "gloo" for the CPU tests of this logic).
+
+``predict_sharded`` is the synchronous form; ``ShardedPredictor`` is the same path with the gather issued
+asynchronously into a ring of buffers, so that step i's gather (xGMI) overlaps step i+1's compute --
+``bench.py --gpus N`` runs exactly this class.
 """
 
 from __future__ import annotations
 
-from typing import Callable, Optional, Tuple
+from typing import Callable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
 
+Predict = Callable[[torch.Tensor, torch.Tensor], Tuple[torch.Tensor, torch.Tensor]]
+
 
 def shard_bounds(n_pairs: int, rank: int, world: int) -> Tuple[int, int]:
-    """Contiguous shard [lo, hi) of ``n_pairs`` for ``rank``; sizes differ by at most one pair."""
+    """Contiguous shard [lo, hi) of ``n_pairs`` for ``rank``; sizes differ by at most one pair
+    (ranks past ``n_pairs`` get an empty shard and still take part in the gather)."""
     base, extra = divmod(n_pairs, world)
     lo = rank * base + min(rank, extra)
     return lo, lo + base + (1 if rank < extra else 0)
@@ -27,8 +34,98 @@ def pack_result(flow: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     return torch.cat([flow, mask.unsqueeze(1)], dim=1).contiguous()
 
 
+def _unpack(gathered: torch.Tensor, n_pairs: int, world: int, max_b: int) -> torch.Tensor:
+    parts = []
+    for r in range(world):
+        lo, hi = shard_bounds(n_pairs, r, world)
+        parts.append(gathered[r * max_b : r * max_b + (hi - lo)])
+    return torch.cat(parts, dim=0)
+
+
+class ShardedPredictor:
+    """Runs ``predict`` on this rank's shard of every global batch and gathers all ranks' results.
+
+    ``submit(source, target)`` launches the shard's compute and the (asynchronous) all_gather of its packed
+    result into ring slot ``i % depth``; ``result(i)`` waits for that gather and returns ``(flow, mask)`` of ALL
+    pairs in global order.  A slot is reused ``depth`` submits later (its gather is waited for first).
+    A rank whose shard is empty (fewer pairs than ranks) skips ``predict`` and contributes a zero pad, so no rank
+    ever misses the collective."""
+
+    def __init__(self, predict: Predict, group=None, depth: int = 2):
+        self.predict, self.group, self.depth = predict, group, depth
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self._slots: List[Optional[dict]] = [None] * depth
+        self._count = 0
+
+    def _buffers(self, slot: int, max_b: int, tail: Tuple[int, ...], like: torch.Tensor) -> dict:
+        s = self._slots[slot]
+        shape = (max_b,) + tail
+        if s is None or s["pad"].shape != shape or s["pad"].device != like.device:
+            s = dict(
+                pad=torch.zeros(shape, dtype=torch.float32, device=like.device),
+                out=torch.empty((self.world * max_b,) + tail, dtype=torch.float32, device=like.device),
+                work=None, n=0, max_b=max_b,
+            )
+            self._slots[slot] = s
+        return s
+
+    def submit(self, source: torch.Tensor, target: torch.Tensor, out_hw: Optional[Tuple[int, int]] = None) -> int:
+        """``source``/``target`` hold the GLOBAL batch (leading dim = all pairs).  ``out_hw``: the result's (H, W),
+        needed only by a rank whose shard is empty (defaults to the source image size)."""
+        n = int(source.shape[0])
+        ticket = self._count
+        slot = ticket % self.depth
+        if self._slots[slot] is not None and self._slots[slot]["work"] is not None:
+            self._slots[slot]["work"].wait()  # the buffers of `depth` submits ago are free again
+            self._slots[slot]["work"] = None
+        lo, hi = shard_bounds(n, self.rank, self.world)
+        max_b = -(-n // self.world)
+        if hi > lo:
+            flow, mask = self.predict(source[lo:hi], target[lo:hi])
+            tail = (3,) + tuple(flow.shape[2:])
+            s = self._buffers(slot, max_b, tail, flow)
+            s["pad"][: hi - lo, :2].copy_(flow)
+            s["pad"][: hi - lo, 2].copy_(mask)
+        else:
+            if out_hw is None:
+                hw = tuple(source.shape[1:3]) if source.shape[-1] == 3 else tuple(source.shape[-2:])
+            else:
+                hw = tuple(out_hw)
+            s = self._buffers(slot, max_b, (3,) + hw, source)
+        if hi - lo < max_b:
+            s["pad"][hi - lo :].zero_()
+        s["n"] = n
+        s["work"] = dist.all_gather_into_tensor(s["out"], s["pad"], group=self.group, async_op=True)
+        self._count += 1
+        return ticket
+
+    def wait(self, ticket: int) -> None:
+        """Wait for the gather of ``ticket`` without assembling the result (stream-level on nccl)."""
+        assert self._count - self.depth <= ticket < self._count, "ticket is no longer (or not yet) in the ring"
+        s = self._slots[ticket % self.depth]
+        if s["work"] is not None:
+            s["work"].wait()
+            s["work"] = None
+
+    def result(self, ticket: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        assert self._count - self.depth <= ticket < self._count, "ticket is no longer (or not yet) in the ring"
+        s = self._slots[ticket % self.depth]
+        if s["work"] is not None:
+            s["work"].wait()
+            s["work"] = None
+        full = _unpack(s["out"], s["n"], self.world, s["max_b"])
+        return full[:, :2], full[:, 2]
+
+    def drain(self) -> None:
+        for s in self._slots:
+            if s is not None and s["work"] is not None:
+                s["work"].wait()
+                s["work"] = None
+
+
 def gather_results(packed_local: torch.Tensor, n_pairs: int, group=None) -> torch.Tensor:
-    """All ranks end up with the packed results of all ``n_pairs`` pairs in global pair order."""
+    """All ranks end up with the packed results of all ``n_pairs`` pairs in global pair order (synchronous)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     max_b = -(-n_pairs // world)
@@ -38,23 +135,13 @@ def gather_results(packed_local: torch.Tensor, n_pairs: int, group=None) -> torc
     pad[: hi - lo] = packed_local
     out = torch.empty((world * max_b,) + tuple(packed_local.shape[1:]), dtype=packed_local.dtype, device=packed_local.device)
     dist.all_gather_into_tensor(out, pad, group=group)
-    parts = []
-    for r in range(world):
-        l, h = shard_bounds(n_pairs, r, world)
-        parts.append(out[r * max_b : r * max_b + (h - l)])
-    return torch.cat(parts, dim=0)
+    return _unpack(out, n_pairs, world, max_b)
 
 
 def predict_sharded(
-    predict: Callable[[torch.Tensor, torch.Tensor], Tuple[torch.Tensor, torch.Tensor]],
-    source: torch.Tensor,
-    target: torch.Tensor,
-    group=None,
+    predict: Predict, source: torch.Tensor, target: torch.Tensor, group=None, out_hw: Optional[Tuple[int, int]] = None
 ) -> Tuple[torch.Tensor, torch.Tensor]:
     """Run ``predict`` on this rank's shard of the global batch and gather everyone's results.
     ``predict(src, tgt) -> (flow (b,2,H,W), covisibility (b,H,W))``."""
-    n = source.shape[0]
-    lo, hi = shard_bounds(n, dist.get_rank(group), dist.get_world_size(group))
-    flow, mask = predict(source[lo:hi], target[lo:hi])
-    full = gather_results(pack_result(flow, mask), n, group)
-    return full[:, :2], full[:, 2]
+    sp = ShardedPredictor(predict, group, depth=1)
+    return sp.result(sp.submit(source, target, out_hw))

@@ -127,8 +127,8 @@ class _Head:
 
 class Engine:
     def __init__(self, model: nn.Module, numerics: str = "fast"):
-        if numerics not in ("fast", "parity"):
-            raise ValueError("numerics must be 'fast' or 'parity'")
+        if numerics not in ("fast", "parity", "parity_x3heads"):
+            raise ValueError("numerics must be 'fast', 'parity' or 'parity_x3heads'")
         hip.lib()  # fail loudly right here if the extension is missing
         self.model = model
         self.numerics = numerics
@@ -180,7 +180,7 @@ class Engine:
         if info.max_num_views < 2:
             raise ValueError("info sharing needs max_num_views >= 2")
         # DPT heads: exact-fp32 MFMA in "parity"; bf16x3 split precision (UFM_BF16X2 activations) in "fast"
-        self.head_split = self.numerics == "fast"
+        self.head_split = self.numerics in ("fast", "parity_x3heads")
         self.heads = {"head1": _Head(m.head1, dev, self.head_split)}
         if hasattr(m, "uncertainty_head"):
             self.heads["uncertainty_head"] = _Head(m.uncertainty_head, dev, self.head_split)
@@ -390,7 +390,20 @@ class Engine:
         res, c0 = {}, 0
         for a in hw.adaptors:
             n = a.required_channels
-            res[a.name] = dict(value=out[:, c0 : c0 + n], logits=logits[:, c0 : c0 + n] if logits is not None else None, kind=a.cls_name)
+            raw = out[:, c0 : c0 + n]
+            if a.cls_name == "Covariance2DAdaptor":  # ufm.py:648-651
+                raw = raw.contiguous()
+                cov, inv = torch.empty_like(raw), torch.empty_like(raw)
+                logdet = torch.empty((B, 1, H, W), device=self.dev, dtype=torch.float32)
+                hip.adaptor_covariance2d(raw, B, H * W, cov, inv, logdet)
+                res[a.name] = dict(covariance=cov, inv_covariance=inv, log_det=logdet, kind=a.cls_name)
+            elif a.cls_name == "ConfidenceAdaptor":  # ufm.py:653-654
+                raw = raw.contiguous()
+                val = torch.empty_like(raw)
+                hip.adaptor_confidence(raw, a.confidence_type, a.vmin, a.vmax, val)
+                res[a.name] = dict(value=val, logits=None, kind=a.cls_name)
+            else:
+                res[a.name] = dict(value=raw, logits=logits[:, c0 : c0 + n] if logits is not None else None, kind=a.cls_name)
             c0 += n
         return res
 

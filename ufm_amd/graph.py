@@ -1,0 +1,52 @@
+"""HIP-graph replay of ``predict_correspondences_batched`` for one (batch, layout, dtype, size) signature.
+
+At batch 1 the ~700 ctypes launches of a forward cost as much host time as the kernels take on the GPU
+("Launch path"); every C-ABI entry point is asynchronous on the current stream, allocates nothing and
+never synchronises, so the whole call is capturable.  ``GraphedPredictor`` warms the engine up eagerly (tables,
+workspace, packed weights), captures one call into a ``torch.cuda.CUDAGraph`` (a hipGraph on ROCm) with static
+input / output buffers, and afterwards ``__call__`` = two device copies + one graph launch.  Results are bitwise
+those of the eager call (same kernels, same order, same workspace; tests/test_model_gpu.py).
+
+The returned tensors are the graph's static outputs: they are overwritten by the next call (clone to keep).
+"""
+
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .base import UFMOutputInterface
+
+
+class GraphedPredictor:
+    def __init__(self, model, source_image: torch.Tensor, target_image: torch.Tensor, data_norm_type: Optional[str] = None, warmup: int = 2):
+        if not (source_image.is_cuda and target_image.is_cuda):
+            raise RuntimeError("GraphedPredictor needs device tensors (ufm_amd has no CPU path)")
+        self.model, self.norm = model, data_norm_type
+        self._src = source_image.clone()
+        self._tgt = target_image.clone()
+        eng = model.engine()
+        saved_mb = eng.micro_batches
+        eng.micro_batches = 1  # one stream, one host thread: the capture records a single linear launch sequence
+        try:
+            side = torch.cuda.Stream(device=source_image.device)
+            side.wait_stream(torch.cuda.current_stream(source_image.device))
+            with torch.cuda.stream(side):
+                for _ in range(max(1, warmup)):  # builds tables / workspace / packed weights outside the capture
+                    model.predict_correspondences_batched(self._src, self._tgt, data_norm_type)
+            torch.cuda.current_stream(source_image.device).wait_stream(side)
+            torch.cuda.synchronize(source_image.device)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._out = model.predict_correspondences_batched(self._src, self._tgt, data_norm_type)
+        finally:
+            eng.micro_batches = saved_mb
+
+    def __call__(self, source_image: torch.Tensor, target_image: torch.Tensor) -> UFMOutputInterface:
+        if source_image.shape != self._src.shape or source_image.dtype != self._src.dtype or target_image.shape != self._tgt.shape:
+            raise ValueError("GraphedPredictor was captured for a different input signature")
+        self._src.copy_(source_image, non_blocking=True)
+        self._tgt.copy_(target_image, non_blocking=True)
+        self.graph.replay()
+        return self._out

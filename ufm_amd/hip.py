@@ -46,9 +46,15 @@ SIGNATURES = {
     "ufm_conv2d_nhwc_bf16x3": [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "ufm_upsample_bilinear_nhwc": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp],
     "ufm_head_tail": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _ip, _fp3, _fp3, _vp, _vp, _vp],
+    "ufm_adaptor_covariance2d": [_vp, _i, _i, _vp, _vp, _vp, _vp],
+    "ufm_adaptor_confidence": [_vp, _i64, _i, _f, _f, _vp, _vp],
     "ufm_unmap_flow": [_vp, _i, _i, _i, _ip, _ip, _ip, _i, _i, _vp, _vp, _vp],
     "ufm_unmap_channels": [_vp, _i, _i, _i, _i, _ip, _ip, _i, _i, _fp3, _vp, _vp, _vp],
     "ufm_refine": [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
+    "ufm_image_to_nhwc": [_vp, _i, _i, _i, _i, _i, _fp3, _fp3, _vp, _i, _i, _vp],
+    "ufm_maxpool2x2_nhwc": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "ufm_resize_nearest_nhwc": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp],
+    "ufm_unet_combine": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "ufm_pixel_shuffle_planar": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
     "ufm_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
     "ufm_add_f32": [_vp, _vp, _vp, _i64, _vp],
@@ -249,9 +255,43 @@ def unmap_channels(chan, B, Cc, h, w, rep0, src0, H0, W0, out, valid=None, chan_
     _check(lib().ufm_unmap_channels(_p(chan), B, Cc, h, w, _i4(rep0), _i4(src0), H0, W0, cs, _p(out), _p(valid), _stream()), "ufm_unmap_channels")
 
 
+def adaptor_covariance2d(raw, B, HW, cov, inv_cov, log_det):
+    _check(lib().ufm_adaptor_covariance2d(_p(raw), B, HW, _p(cov), _p(inv_cov), _p(log_det), _stream()), "ufm_adaptor_covariance2d")
+
+
+def adaptor_confidence(raw, kind: int, vmin: float, vmax: float, out):
+    _check(lib().ufm_adaptor_confidence(_p(raw), raw.numel(), kind, float(vmin), float(vmax), _p(out), _stream()), "ufm_adaptor_confidence")
+
+
 def refine(flow, feat, B, Cc, H, W, P, temperature, bias, residual, log_softmax=None):
     _t("ufm_refine", 4.0 * B * H * W * (2 * Cc + 4 + (P * P if log_softmax is not None else 0)))  # both feature maps once, flow, residual, log-softmax
     _check(lib().ufm_refine(_p(flow), _p(feat), B, Cc, H, W, P, temperature, _p(bias), _p(residual), _p(log_softmax), _stream()), "ufm_refine")
+
+
+def _fmt(t: torch.Tensor) -> int:
+    """NHWC activation format of a head/UNet buffer: fp32, or the split format (leading dim 2, bf16)."""
+    return BF16X2 if t.dtype == torch.bfloat16 else F32
+
+
+def image_to_nhwc(img, layout, B, H, W, scale3, shift3, out, Cpad):
+    in_dtype = 0 if img.dtype == torch.uint8 else 1
+    _t("ufm_image_to_nhwc", float(B) * H * W * (3 * img.element_size() + 4 * Cpad))
+    _check(lib().ufm_image_to_nhwc(_p(img), in_dtype, layout, B, H, W, _f3(scale3), _f3(shift3), _p(out), _fmt(out), Cpad, _stream()), "ufm_image_to_nhwc")
+
+
+def maxpool2x2(x, B, H, W, Cc, out):
+    _t("ufm_maxpool2x2_nhwc", 4.0 * B * Cc * (H * W + (H // 2) * (W // 2)))
+    _check(lib().ufm_maxpool2x2_nhwc(_p(x), _fmt(x), B, H, W, Cc, _p(out), _stream()), "ufm_maxpool2x2_nhwc")
+
+
+def resize_nearest(x, B, H, W, Cc, out, Ho, Wo, ldc, c_off):
+    _t("ufm_resize_nearest_nhwc", 8.0 * B * Ho * Wo * Cc)
+    _check(lib().ufm_resize_nearest_nhwc(_p(x), _fmt(x), B, H, W, Cc, _p(out), Ho, Wo, ldc, c_off, _stream()), "ufm_resize_nearest_nhwc")
+
+
+def unet_combine(cls, unet, N, HW, ldu, w1, b1, w2, b2, method, out):
+    _t("ufm_unet_combine", 4.0 * N * HW * 48)
+    _check(lib().ufm_unet_combine(_p(cls), _p(unet), _fmt(unet), N, HW, ldu, _p(w1), _p(b1), _p(w2), _p(b2), method, _p(out), _stream()), "ufm_unet_combine")
 
 
 def pixel_shuffle_planar(x, B, gh, gw, Cc, p, out):

@@ -260,11 +260,18 @@ class AdaptorSpec(_Holder):
         elif cls_name == "MaskAdaptor":
             self.required_channels = 1
             self.kinds, self.scale, self.shift = [1], [1.0], [0.0]
+        elif cls_name == "Covariance2DAdaptor":
+            # raw channels out of the tail kernel (kind 0, a = 1, d = 0); ufm_adaptor_covariance2d finishes them
+            self.required_channels = 3
+            self.kinds, self.scale, self.shift = [0, 0, 0], [1.0] * 3, [0.0] * 3
+        elif cls_name == "ConfidenceAdaptor":
+            self.required_channels = 1
+            self.kinds, self.scale, self.shift = [0], [1.0], [0.0]
+            ctype = kw.get("confidence_type", "exp")
+            self.confidence_type = {"exp": 0, "sigmoid": 1}.get(ctype, 2)
+            self.vmin, self.vmax = float(kw.get("vmin", 1.0)), float(kw.get("vmax", float("inf")))
         else:
-            raise NotImplementedError(
-                f"adaptor {cls_name} is not on the UFM-Base/Refine inference path built so far "
-                "(flow covariance / keypoint confidence: SURVEY 8(f) rank 3)"
-            )
+            raise NotImplementedError(f"adaptor {cls_name} has no call site on the UFM inference path (ufm.py:644-660)")
 
 
 class AdaptorMap(_Holder):

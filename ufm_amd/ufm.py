@@ -29,21 +29,19 @@ from .base import (
 )
 
 
-def modify_state_dict(original_state_dict, mappings):
-    """Rename / drop checkpoint keys by substring (ufm.py:85-117): first matching rule wins, None drops."""
-    out = {}
-    for key, value in original_state_dict.items():
-        new_key, drop = key, False
-        for old, new in mappings.items():
-            if old in key:
-                if new is None:
-                    drop = True
-                else:
-                    new_key = key.replace(old, new)
-                break
-        if not drop:
-            out[new_key] = value
-    return out
+from .keymap import load_checked, modify_state_dict  # noqa: E402,F401  (modify_state_dict: reference name, ufm.py:85)
+
+
+def _package_uncertainty(result: UFMOutputInterface, hu: Dict[str, Any]) -> None:
+    """The uncertainty head's named outputs (ufm.py:644-660): covariance triple, keypoint confidence, covisibility."""
+    if "flow_cov" in hu:
+        result.flow.flow_covariance = hu["flow_cov"]["covariance"]
+        result.flow.flow_covariance_inv = hu["flow_cov"]["inv_covariance"]
+        result.flow.flow_covariance_log_det = hu["flow_cov"]["log_det"]
+    if "keypoint_confidence" in hu:
+        result.keypoint_confidence = hu["keypoint_confidence"]["value"].squeeze(1)
+    if "non_occluded_mask" in hu:
+        result.covisibility = UFMMaskFieldOutput(mask=hu["non_occluded_mask"]["value"], logits=hu["non_occluded_mask"]["logits"])
 
 
 class UniFlowMatch(UniFlowMatchModelsBase, PyTorchModelHubMixin):
@@ -79,13 +77,10 @@ class UniFlowMatch(UniFlowMatchModelsBase, PyTorchModelHubMixin):
         self.head1: nn.Module = M.make_head(head_type, feature_head_kwargs, adaptors_kwargs)
         if pretrained_checkpoint_path is not None:  # ufm.py:198-217
             ckpt = torch.load(pretrained_checkpoint_path, map_location="cpu", weights_only=True)
-            if "state_dict" in ckpt:
-                sd = {k[6:]: v for k, v in ckpt["state_dict"].items() if k.startswith("model.")}
-                sd = modify_state_dict(sd, {"feature_matching_proj": None, "encoder.model.mask_token": None})
-                self.load_state_dict(sd, strict=True)
+            if "state_dict" in ckpt:  # Lightning training checkpoint: "model." prefix, dropped keys (keymap.py)
+                load_checked(self, ckpt["state_dict"], lightning=True, what=pretrained_checkpoint_path)
             else:
-                result = self.load_state_dict(ckpt["model"], strict=False)
-                assert len(result.missing_keys) == 0, f"Missing keys: {result.missing_keys}"
+                load_checked(self, ckpt["model"], what=pretrained_checkpoint_path)
 
     @classmethod
     def from_pretrained_ckpt(cls, pretrained_model_name_or_path, strict=True, **kw):
@@ -93,9 +88,34 @@ class UniFlowMatch(UniFlowMatchModelsBase, PyTorchModelHubMixin):
         if os.path.isfile(pretrained_model_name_or_path):
             ckpt = torch.load(pretrained_model_name_or_path, map_location="cpu", weights_only=True)
             model = cls(**ckpt["model_args"])
-            model.load_state_dict(ckpt["model"], strict=strict)
+            if strict:
+                model.load_state_dict(ckpt["model"], strict=True)
+            else:  # never silently: missing parameters raise, extra keys must be on keymap.ALLOWED_UNEXPECTED
+                load_checked(model, ckpt["model"], what=pretrained_model_name_or_path)
             return model
         raise ValueError(f"Pretrained model {pretrained_model_name_or_path} not found.")
+
+    # PyTorchModelHubMixin.from_pretrained ends here.  The mixin's default is load(strict=False) with no check at all:
+    # a parameter whose name differs would silently keep its random init.  Both loaders go through
+    # keymap.load_checked instead -- missing parameters raise, as the reference asserts at ufm.py:216-217.
+    @classmethod
+    def _load_as_safetensor(cls, model, model_file: str, map_location: str, strict: bool):
+        from safetensors.torch import load_file
+
+        load_checked(model, load_file(model_file, device="cpu"), what=model_file)
+        if map_location != "cpu":
+            model.to(map_location)
+        model.eval()
+        return model
+
+    @classmethod
+    def _load_as_pickle(cls, model, model_file: str, map_location: str, strict: bool):
+        sd = torch.load(model_file, map_location="cpu", weights_only=True)  # nothing from the file is executed
+        load_checked(model, sd, what=model_file)
+        if map_location != "cpu":
+            model.to(map_location)
+        model.eval()
+        return model
 
     # ------------------------------------------------------------------ forward
     def _check_views(self, view1, view2):
@@ -185,9 +205,7 @@ class UniFlowMatchConfidence(UniFlowMatch, PyTorchModelHubMixin):
     def _package(self, raw: Dict[str, Any]) -> UFMOutputInterface:
         result = UFMOutputInterface()
         result.flow = UFMFlowFieldOutput(flow_output=raw["head1"]["flow"]["value"])
-        hu = raw["uncertainty_head"]
-        if "non_occluded_mask" in hu:
-            result.covisibility = UFMMaskFieldOutput(mask=hu["non_occluded_mask"]["value"], logits=hu["non_occluded_mask"]["logits"])
+        _package_uncertainty(result, raw["uncertainty_head"])
         return result
 
     def get_parameter_groups(self) -> Dict[str, torch.nn.ParameterList]:
@@ -259,9 +277,8 @@ class UniFlowMatchClassificationRefinement(UniFlowMatch, PyTorchModelHubMixin):
         ref = raw["refine"]
         B = ref["flow"].shape[0]
         result.flow = UFMFlowFieldOutput(flow_output=ref["flow"])
-        if "uncertainty_head" in raw and "non_occluded_mask" in raw["uncertainty_head"]:
-            hu = raw["uncertainty_head"]["non_occluded_mask"]
-            result.covisibility = UFMMaskFieldOutput(mask=hu["value"], logits=hu["logits"])
+        if "uncertainty_head" in raw:
+            _package_uncertainty(result, raw["uncertainty_head"])
         # quirk kept from the reference: regression_flow_output is the REFINED flow (ufm.py:991,1002)
         result.classification_refinement = UFMClassificationRefinementOutput(
             regression_flow_output=ref["flow"],
