@@ -673,3 +673,76 @@ def test_split_format_layernorm_upsample_tail(hip):
     ot = torch.zeros(B, 2, HW, device=DEV)
     hip.head_tail(split(xt).to(DEV), B * HW, HW, Cin, wt_.to(DEV), bt.to(DEV), 2, [0, 1], [1.0, 1.0], [0.0, 0.0], ot, None)
     assert (ot.cpu()[:, 0] - y[:, 0]).abs().max() <= 2e-4 and (ot.cpu()[:, 1] - torch.sigmoid(y[:, 1])).abs().max() <= 1e-4
+
+
+# ----------------------------------------------------------------------------- UNet layout kernels (R5)
+def to_fmt(x_nhwc, split):
+    """fp32 NHWC -> device buffer in the head format (fp32, or the (2, ...) bf16 split planes)."""
+    if not split:
+        return x_nhwc.to(DEV).contiguous()
+    hi = x_nhwc.to(torch.bfloat16)
+    lo = (x_nhwc - hi.float()).to(torch.bfloat16)
+    return torch.stack([hi, lo]).to(DEV).contiguous()
+
+
+def from_fmt(t):
+    return (t[0].float() + t[1].float()).cpu() if t.dtype == torch.bfloat16 else t.cpu()
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_unet_layout_kernels(hip, split):
+    """nn.MaxPool2d(2,2), F.interpolate(size) legacy nearest into a concat slot, image normalise + NHWC pad
+    (unet_encoder.py:37-68; base.py:228-229) against torch, fp32 and split format, odd sizes."""
+    B, H, W, C = 2, 13, 27, 16
+    x = rnd(B, H, W, C, seed=1)
+    if split:
+        x = from_fmt(to_fmt(x, True))  # representable values: the kernels move (hi, lo) pairs, they never re-round
+    xd = to_fmt(x, split)
+    shp = lambda *s: ((2,) + s) if split else s  # noqa: E731
+    dt = torch.bfloat16 if split else torch.float32
+    out = torch.zeros(shp(B, H // 2, W // 2, C), device=DEV, dtype=dt)
+    hip.maxpool2x2(xd, B, H, W, C, out)
+    want = F.max_pool2d(x.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    assert torch.equal(from_fmt(out), want)
+    # nearest resize 6x13 -> 13x27 into channels [8, 24) of a 32-channel buffer + a same-size copy into [0, 8)
+    small = rnd(B, 6, 13, C, seed=2)
+    if split:
+        small = from_fmt(to_fmt(small, True))
+    cat = torch.zeros(shp(B, H, W, 32), device=DEV, dtype=dt)
+    hip.resize_nearest(to_fmt(small, split), B, 6, 13, C, cat, H, W, 32, 8)
+    hip.resize_nearest(to_fmt(x[..., :8].contiguous(), split), B, H, W, 8, cat, H, W, 32, 0)
+    got = from_fmt(cat)
+    want = F.interpolate(small.permute(0, 3, 1, 2), size=(H, W)).permute(0, 2, 3, 1)
+    assert torch.equal(got[..., 8:24], want) and torch.equal(got[..., :8], x[..., :8]) and torch.all(got[..., 24:] == 0)
+    # image -> NHWC, 3 -> 32 channels, uint8 BHWC and float BCHW
+    img = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(3))
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    o = torch.full(shp(B, H, W, 32), 7.0, device=DEV, dtype=dt)
+    hip.image_to_nhwc(img.to(DEV), 0, B, H, W, std, mean, o, 32)
+    want = (img.float() / 255.0 - torch.tensor(mean)) / torch.tensor(std)
+    got = from_fmt(o)
+    assert (got[..., :3] - want).abs().max() <= (1e-6 if not split else 2e-5) and torch.all(got[..., 3:] == 0)
+    imgf = rnd(B, 3, H, W, seed=4)
+    hip.image_to_nhwc(imgf.to(DEV), 1, B, H, W, [1.0] * 3, [0.0] * 3, o, 32)
+    assert (from_fmt(o)[..., :3] - imgf.permute(0, 2, 3, 1)).abs().max() <= (0 if not split else 2e-5)
+
+
+@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("method", [0, 1])
+def test_unet_combine(hip, split, method):
+    """ufm.py:967-983: conv2(relu(conv1(cat[cls, unet]))) / conv2(cls * tanh(unet)) per pixel."""
+    N, H, W = 2, 9, 11
+    cls = rnd(N, 16, H, W, seed=1)
+    un = rnd(N, H, W, 32, seed=2)
+    if split:
+        un = from_fmt(to_fmt(un, True))
+    w1, b1 = rnd(32, 32, seed=3, scale=0.2), rnd(32, seed=4, scale=0.1)
+    w2, b2 = rnd(16, 32 if method == 0 else 16, seed=5, scale=0.2), rnd(16, seed=6, scale=0.1)
+    unc = un[..., :16].permute(0, 3, 1, 2)
+    if method == 0:
+        want = F.conv2d(F.relu(F.conv2d(torch.cat([cls, unc], 1), w1[:, :, None, None], b1)), w2[:, :, None, None], b2)
+    else:
+        want = F.conv2d(cls * torch.tanh(unc), w2[:, :, None, None], b2)
+    out = torch.zeros(N, 16, H, W, device=DEV)
+    hip.unet_combine(cls.to(DEV), to_fmt(un, split), N, H * W, 32, w1.to(DEV), b1.to(DEV), w2.to(DEV), b2.to(DEV), method, out)
+    assert (out.cpu() - want).abs().max() <= 2e-5

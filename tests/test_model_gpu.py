@@ -416,8 +416,10 @@ def test_covariance_and_keypoint_confidence_outputs_vs_oracle(env, numerics):
     assert (o.flow.flow_output - p.flow.flow_output.cpu()).abs().max() <= (tol if numerics == "parity" else 0.02 * o.flow.flow_output.abs().max())
     cov_o, cov_p = o.flow.flow_covariance, p.flow.flow_covariance.cpu()
     assert cov_p.shape == (2, 3, 75, 100) == cov_o.shape
-    rel = ((cov_o - cov_p).abs() / (cov_o.abs() + 1e-3)).max().item()
-    assert rel <= (2e-3 if numerics == "parity" else 0.1), rel  # covariance = exp(2 * logit): relative error = 2 x logit error
+    # covariance = exp(2 * logit)-like: the error is relative to the pixel's own scale sqrt(xx * yy) (the xy entry can be ~0)
+    scale = torch.cat([cov_o[:, 0:1], cov_o[:, 1:2], (cov_o[:, 0:1] * cov_o[:, 1:2]).sqrt()], dim=1) + 1e-9
+    rel = ((cov_o - cov_p).abs() / scale).max().item()
+    assert rel <= (2e-3 if numerics == "parity" else 0.15), rel
     assert (o.covisibility.mask - p.covisibility.mask.cpu()).abs().max() <= (1e-3 if numerics == "parity" else 0.02)
     # network-resolution outputs of forward(): inverse covariance, log-determinant, keypoint confidence
     a, b = torch.randn(1, 3, 56, 56, generator=torch.Generator().manual_seed(3)), torch.randn(1, 3, 56, 56, generator=torch.Generator().manual_seed(4))
@@ -429,7 +431,8 @@ def test_covariance_and_keypoint_confidence_outputs_vs_oracle(env, numerics):
     assert (fo.keypoint_confidence - fp.keypoint_confidence.cpu()).abs().max() <= t2
     assert (fo.flow.flow_covariance_log_det - fp.flow.flow_covariance_log_det.cpu()).abs().max() <= 2 * t2
     inv_o, inv_p = fo.flow.flow_covariance_inv, fp.flow.flow_covariance_inv.cpu()
-    assert ((inv_o - inv_p).abs() / (inv_o.abs() + 1e-3)).max() <= 2 * t2
+    iscale = torch.cat([inv_o[:, 0:1], inv_o[:, 1:2], (inv_o[:, 0:1] * inv_o[:, 1:2]).sqrt()], dim=1) + 1e-9
+    assert ((inv_o - inv_p).abs() / iscale).max() <= 2 * t2
     # cov . inv_cov = I per pixel (property of the kernel's own outputs)
     c, i = fp.flow.flow_covariance.cpu().double(), fp.flow.flow_covariance_inv.cpu().double()
     assert (c[:, 0] * i[:, 0] + c[:, 2] * i[:, 2] - 1).abs().max() <= 1e-3 and (c[:, 0] * i[:, 2] + c[:, 2] * i[:, 1]).abs().max() <= 1e-3
@@ -461,3 +464,88 @@ def test_covariance_unmap_against_reference_golden(env, golden_dir, name):
     cov = p.flow.flow_covariance.cpu().numpy()
     assert cov.shape == g["cov_out"].shape
     assert np.abs(cov - g["cov_out"]).max() <= 1e-5 * max(1.0, float(np.abs(g["cov_out"]).max()))
+
+
+@pytest.mark.parametrize("numerics", ["parity", "fast"])
+def test_unet_forward_against_reference_golden(env, golden_dir, numerics):
+    """R5, pinned: Engine._unet (conv kernels + max-pool / nearest / concat kernels) vs the output of the reference's own
+    UNet class (tests/golden/unet_full_odd.npz: features [64,128,256,512], 42x70 input: 42->21->10->5->2 with the nearest
+    fix-up of unet_encoder.py:66-67 at two levels).  Same weights by the same seeded initialiser."""
+    ufm_amd, R = env
+    from ufm_amd import hip
+
+    g = np.load(os.path.join(golden_dir, "unet_full_odd.npz"))
+    prod = ufm_amd.UniFlowMatchClassificationRefinement(**ufm_amd.ufm_tiny_config(refine=True, use_unet_feature=True)).eval()
+    ufm_amd.modules.init_weights_(prod, 0)
+    ufm_amd.modules.init_weights_(prod.unet_feature, int(g["seed"]))  # the generator called init_weights_(reference UNet, seed)
+    wsum = float(sum(p.double().abs().sum() for p in prod.unet_feature.parameters()))
+    assert abs(wsum - float(g["weight_abs_sum"])) <= 1e-6 * wsum
+    prod = prod.to(DEV).set_numerics(numerics)
+    eng = prod.engine()
+    eng._pack()
+    eng._tls.ns = ""
+    x = torch.from_numpy(g["x"]).to(DEV)
+    n, _, h, w = x.shape
+    with torch.cuda.device(x.device):
+        img = eng.hbuf("t_un_img", (n, h, w, 32))
+        hip.image_to_nhwc(x, 1, n, h, w, [1.0] * 3, [0.0] * 3, img, 32)
+        out = eng._unet(img, n, h, w)
+    got = (out[0].float() + out[1].float()) if out.dtype == torch.bfloat16 else out
+    got = got[..., :16].permute(0, 3, 1, 2).cpu().numpy()
+    err = np.abs(got - g["y"]).max()
+    print(f"UNet vs reference golden [{numerics}]: max-abs {err:.3g} (range {np.abs(g['y']).max():.3g})")
+    assert err <= 1e-3 * max(1.0, float(np.abs(g["y"]).max()))
+
+
+@pytest.mark.parametrize("method", ["conv", "modulate"])
+def test_refine_with_unet_against_reference_wiring_golden(env, golden_dir, method):
+    """The reference's real UFM-Refine forward with use_unet_feature=True on the restated blocks (make_goldens.py)."""
+    ufm_amd, R = env
+    g = np.load(os.path.join(golden_dir, f"wiring_refine_unet_{method}.npz"))
+    kw = dict(refine=True, use_unet_feature=True, feature_combine_method=method)
+    oracle = R.UFMRef(**R.ufm_tiny_config(**kw)).eval()
+    R.init_weights_(oracle, int(g["seed"]))
+    prod = ufm_amd.UniFlowMatchClassificationRefinement(**ufm_amd.ufm_tiny_config(**kw)).eval()
+    prod.load_state_dict(oracle.state_dict(), strict=True)
+    prod = prod.to(DEV).set_numerics("parity")
+    p = prod.predict_correspondences_batched(torch.from_numpy(g["src"]).to(DEV), torch.from_numpy(g["tgt"]).to(DEV))
+    assert np.abs(p.flow.flow_output.cpu().numpy() - g["flow"]).max() <= 1e-3
+    assert np.abs(p.covisibility.mask.cpu().numpy() - g["mask"]).max() <= 1e-3
+    s_n, t_n = R.to_bchw_normalised(torch.from_numpy(g["src"]), torch.from_numpy(g["tgt"]), "dinov2", None)
+    v = lambda t: {"img": t.to(DEV), "symmetrized": False, "data_norm_type": "dinov2"}  # noqa: E731
+    low = prod(v(s_n), v(t_n))
+    fm = low.classification_refinement.feature_map_0.cpu().numpy()
+    assert np.abs(fm - g["feature_map_0"]).max() <= 1e-3 * max(1.0, float(np.abs(g["feature_map_0"]).max()))
+    assert np.abs(low.classification_refinement.residual.cpu().numpy() - g["residual"]).max() <= 2e-3
+    # both numerics modes, resized unequal inputs (UNet input = the resized normalised image), vs the oracle
+    src, tgt = u8((2, 75, 100, 3), 5), u8((2, 60, 90, 3), 6)
+    o = oracle.predict_correspondences_batched(src, tgt)
+    pp = prod.predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
+    df, dm, mx = compare(o, pp)
+    assert df <= 2e-3 and dm <= 1e-3, (df, dm, mx)
+    pf = prod.set_numerics("fast").predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
+    df2, dm2, _ = compare(o, pf)
+    assert df2 <= 0.03 * mx + 0.02 and dm2 <= 0.02, (df2, dm2, mx)
+
+
+def test_config4_variant_refine_with_unet_full_size(env):
+    """SURVEY 8(a) R5 "config 4 variant": UFM-Refine with use_unet_feature=True at 518x518 (518 is not a multiple of 16:
+    259 -> 129 -> 64 -> 32 exercises the nearest fix-up twice), B=1, parity mode <= 1e-3 px vs the fp32 CPU oracle; the
+    fast mode bounded."""
+    ufm_amd, R = env
+    oracle = R.UFMRef(**R.make_config(refine=True, enc_indices=[5, 23], use_unet_feature=True)).eval()
+    R.init_weights_(oracle, 0)
+    prod = ufm_amd.UniFlowMatchClassificationRefinement(**ufm_amd.ufm_refine_config(use_unet_feature=True)).eval()
+    prod.load_state_dict(oracle.state_dict(), strict=True)
+    prod = prod.to(DEV)
+    src, tgt = u8((1, 518, 518, 3), 77), u8((1, 518, 518, 3), 78)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    o = oracle.predict_correspondences_batched(src, tgt)
+    p = prod.set_numerics("parity").predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
+    df, dm, mx = compare(o, p)
+    print(f"UFM-Refine + UNet 518 parity mode: flow max-abs {df:.3g} px (range {mx:.3g}), mask {dm:.3g}")
+    assert df <= 1e-3 and dm <= 1e-3, (df, dm, mx)
+    pf = prod.set_numerics("fast").predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
+    df2, dm2, _ = compare(o, pf)
+    print(f"UFM-Refine + UNet 518 fast mode: flow max-abs {df2:.3g} px, mask {dm2:.3g}")
+    assert df2 <= 0.03 * mx and dm2 <= 0.02, (df2, dm2, mx)

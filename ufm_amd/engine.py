@@ -79,9 +79,17 @@ class _Conv:
     """Conv2d packed [Cout][KH][KW][Cin]; ConvTranspose2d(k == s) packed [(kh,kw,co)][Cin].
     split=True stores the weight pre-split in the UFM_BF16X2 format for the bf16x3 kernel."""
 
-    def __init__(self, conv: nn.Module, dev, split: bool = False):
+    def __init__(self, conv: nn.Module, dev, split: bool = False, cin_pad: int = 0, cout_pad: int = 0):
         w = conv.weight.detach().to(device=dev, dtype=torch.float32)
         self.b = _f32(conv.bias, dev) if conv.bias is not None else None
+        if cin_pad or cout_pad:  # zero-pad to the kernels' channel multiples (UNet: 3 input channels, 16 output channels)
+            assert isinstance(conv, nn.Conv2d)
+            co, ci = w.shape[0], w.shape[1]
+            wp = torch.zeros((max(co, cout_pad), max(ci, cin_pad)) + tuple(w.shape[2:]), device=dev, dtype=torch.float32)
+            wp[:co, :ci] = w
+            w = wp
+            if self.b is not None and cout_pad > co:
+                self.b = torch.cat([self.b, torch.zeros(cout_pad - co, device=dev)])
         if isinstance(conv, nn.ConvTranspose2d):
             cin, co, kh, kw = w.shape
             assert kh == kw == conv.stride[0] == conv.stride[1] and conv.padding == (0, 0)
@@ -191,8 +199,22 @@ class Engine:
             self.cls_fc2 = _Lin(ch.mlp.fc2, dev, torch.float32)
             self.cls_out_dim = ch.output_dim
             self.cls_bias = _f32(m.classification_bias, dev)
-            if getattr(m, "use_unet_feature", False):
-                raise NotImplementedError("use_unet_feature=True (UNet fine features) is not built yet")
+            self.unet = None
+            if getattr(m, "use_unet_feature", False):  # unet_encoder.py:26-71 + ufm.py:818-825
+                u, sp = m.unet_feature, self.head_split
+                dc = lambda d, first=False: (_Conv(d.conv[0], dev, sp, cin_pad=32 if first else 0), _Conv(d.conv[2], dev, sp))  # noqa: E731
+                self.unet = dict(
+                    downs=[dc(d, i == 0) for i, d in enumerate(u.downs)],
+                    bottleneck=dc(u.bottleneck),
+                    ups=[(_Conv(u.ups[k], dev, sp), dc(u.ups[k + 1])) for k in range(0, len(u.ups), 2)],
+                    final=_Conv(u.final_conv, dev, sp, cout_pad=32),
+                )
+                assert u.out_channels == 16 and self.cls_out_dim == 16, "the combine step is built for 16 + 16 feature channels (ufm.py:818-825)"
+                self.unet_method = 0 if m.feature_combine_method == "conv" else 1
+                self.unet_w1 = _f32(m.conv1.weight.reshape(m.conv1.weight.shape[0], -1), dev)
+                self.unet_b1 = _f32(m.conv1.bias, dev)
+                self.unet_w2 = _f32(m.conv2.weight.reshape(m.conv2.weight.shape[0], -1), dev)
+                self.unet_b2 = _f32(m.conv2.bias, dev)
         self.zero = torch.zeros(256, device=dev, dtype=torch.float32)
         for d, what in ((self.D, "encoder dim"), (self.Di, "info-sharing dim")):
             if self.numerics == "fast" and (d % 128 != 0):
@@ -407,6 +429,45 @@ class Engine:
             c0 += n
         return res
 
+    # ------------------------------------------------------------------ UNet fine features (UFM-Refine option)
+    def _unet(self, img: torch.Tensor, N: int, H: int, W: int) -> torch.Tensor:
+        """unet_encoder.py:50-71 on NHWC maps: (conv3x3+ReLU) x 2 / max-pool down, ConvTranspose(k=s=2) up, nearest fix-up
+        of odd sizes, concat (skip | up), (conv3x3+ReLU) x 2, final 1x1.  ``img``: (N, H, W, 32) head-format buffer holding
+        the normalised image in channels 0..2.  Returns (N, H, W, 32) with the 16 feature channels first."""
+        un = self.unet
+        x, h, w = img, H, W
+        skips = []
+        for i, (c1, c2) in enumerate(un["downs"]):  # :53-57
+            t = self.hbuf(f"un_d{i}a", (N, h, w, c1.cout))
+            self.conv(x, N, h, w, c1, t, act=hip.ACT_RELU)
+            s = self.hbuf(f"un_d{i}b", (N, h, w, c2.cout))
+            self.conv(t, N, h, w, c2, s, act=hip.ACT_RELU)
+            skips.append((s, h, w, c2.cout))
+            x = self.hbuf(f"un_p{i}", (N, h // 2, w // 2, c2.cout))
+            hip.maxpool2x2(s, N, h, w, c2.cout, x)
+            h, w = h // 2, w // 2
+        c1, c2 = un["bottleneck"]
+        t = self.hbuf("un_ba", (N, h, w, c1.cout))
+        self.conv(x, N, h, w, c1, t, act=hip.ACT_RELU)
+        x = self.hbuf("un_bb", (N, h, w, c2.cout))
+        self.conv(t, N, h, w, c2, x, act=hip.ACT_RELU)
+        for k, (ct, (c1, c2)) in enumerate(un["ups"]):  # :62-69
+            skip, sh, sw, sc = skips[-1 - k]
+            f = ct.cout // (ct.shuffle * ct.shuffle)
+            up = self.hbuf(f"un_u{k}", (N, 2 * h, 2 * w, f))
+            self.conv(x, N, h, w, ct, up)
+            cat = self.hbuf(f"un_c{k}", (N, sh, sw, sc + f))
+            hip.resize_nearest(skip, N, sh, sw, sc, cat, sh, sw, sc + f, 0)        # torch.cat((skip, x), dim=1): skip half
+            hip.resize_nearest(up, N, 2 * h, 2 * w, f, cat, sh, sw, sc + f, sc)    # F.interpolate(x, size=skip.shape[2:]) | copy
+            h, w = sh, sw
+            t = self.hbuf(f"un_u{k}a", (N, h, w, c1.cout))
+            self.conv(cat, N, h, w, c1, t, act=hip.ACT_RELU)
+            x = self.hbuf(f"un_u{k}b", (N, h, w, c2.cout))
+            self.conv(t, N, h, w, c2, x, act=hip.ACT_RELU)
+        out = self.hbuf("un_out", (N, H, W, un["final"].cout))
+        self.conv(x, N, H, W, un["final"], out)
+        return out
+
     # ------------------------------------------------------------------ full forward
     @torch.no_grad()
     def forward(self, src, tgt, *, layout: int, scale3, shift3, H: int, W: int, Hs: int, Ws: int, Ht: int, Wt: int) -> Dict[str, Any]:
@@ -490,18 +551,25 @@ class Engine:
         gh, gw = H // self.P, W // self.P
         Np = gh * gw
         patches = self.buf("patches", (B2 * Np, KPAD), self.adt)
+        want_unet = self.refine and self.unet is not None
+        # view["img"] of ufm.py:915-917 per view: normalised, network resolution, NHWC with 3 -> 32 zero-padded channels
+        unet_imgs = [self.hbuf(f"un_img{v}", (B, H, W, 32)) for v in range(2)] if want_unet else None
         for v, (img, h0, w0) in enumerate(((src, Hs, Ws), (tgt, Ht, Wt))):
             dst = patches[v * B * Np : (v + 1) * B * Np]
             if (h0, w0) == (H, W):
                 hip.patchify(img, layout, B, H, W, self.P, scale3, shift3, dst, KPAD)
+                if want_unet:
+                    hip.image_to_nhwc(img, layout, B, H, W, scale3, shift3, unet_imgs[v], 32)
             else:  # normalise-on-load + separable antialias resize (flow_resizing.py:313-326), then patchify
                 rs = self.buf(f"resized{v}", (B, 3, H, W))
                 tmp = self.buf(f"resize_tmp{v}", (B * 3 * h0 * W,))
                 hip.resize_antialias(img, layout, B, h0, w0, scale3, shift3, rs, H, W, tmp)
                 hip.patchify(rs, 1, B, H, W, self.P, [1.0, 1.0, 1.0], [0.0, 0.0, 0.0], dst, KPAD)
-        return self._forward_patches(patches, B, H, W)
+                if want_unet:
+                    hip.image_to_nhwc(rs, 1, B, H, W, [1.0, 1.0, 1.0], [0.0, 0.0, 0.0], unet_imgs[v], 32)
+        return self._forward_patches(patches, B, H, W, unet_imgs)
 
-    def _forward_patches(self, patches, B: int, H: int, W: int) -> Dict[str, Any]:
+    def _forward_patches(self, patches, B: int, H: int, W: int, unet_imgs: Optional[List[torch.Tensor]] = None) -> Dict[str, Any]:
         B2 = 2 * B
         gh, gw = H // self.P, W // self.P
         x, Np, N = self._encode(patches, B2, H, W)
@@ -596,6 +664,13 @@ class Engine:
             self.linear(hidden, self.cls_fc2, B2 * Np, tok)
             feats = torch.empty((B2, self.cls_out_dim, H, W), device=self.dev)
             hip.pixel_shuffle_planar(tok, B2, gh, gw, self.cls_out_dim, self.P, feats)
+            if self.unet is not None:  # ufm.py:915-917, :967-983: one UNet pass per view, then the per-pixel combine
+                combined = torch.empty_like(feats)
+                for v in range(2):
+                    uf = self._unet(unet_imgs[v], B, H, W)
+                    hip.unet_combine(feats[v * B : (v + 1) * B], uf, B, H * W, uf.shape[-1], self.unet_w1, self.unet_b1, self.unet_w2, self.unet_b2,
+                                     self.unet_method, combined[v * B : (v + 1) * B])
+                feats = combined
             flow = out["head1"]["flow"]["value"]
             residual = torch.empty_like(flow)
             m = self.model

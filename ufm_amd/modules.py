@@ -246,6 +246,34 @@ class MLPFeatureParams(_Holder):
         self.mlp = _MlpParams(input_feature_dim, int(mlp_ratio * input_feature_dim), output_dim * patch_size * patch_size)
 
 
+class _DoubleConvParams(_Holder):
+    """unet_encoder.py:10-23: parameters of (Conv3x3 pad 1 -> ReLU) x 2 under the reference's names conv.0 / conv.2."""
+
+    def __init__(self, cin: int, cout: int):
+        super().__init__()
+        self.conv = nn.ModuleList([nn.Conv2d(cin, cout, kernel_size=3, padding=1), nn.Identity(), nn.Conv2d(cout, cout, kernel_size=3, padding=1), nn.Identity()])
+
+
+class UNetParams(_Holder):
+    """Parameters of unet_encoder.py:26-71 with the reference's attribute names (state-dict keys ``downs.N.conv.{0,2}.*``,
+    ``ups.{2k}.*`` = ConvTranspose2d(k=s=2), ``ups.{2k+1}.conv.{0,2}.*``, ``bottleneck.conv.{0,2}.*``, ``final_conv.*``).
+    The forward pass is Engine._unet (implicit-GEMM conv kernels + ufm_maxpool2x2_nhwc / ufm_resize_nearest_nhwc)."""
+
+    def __init__(self, in_channels: int, out_channels: int, features=(64, 128, 256, 512)):
+        super().__init__()
+        self.in_channels, self.out_channels, self.features = in_channels, out_channels, list(features)
+        self.downs, self.ups = nn.ModuleList(), nn.ModuleList()
+        c = in_channels
+        for f in features:
+            self.downs.append(_DoubleConvParams(c, f))
+            c = f
+        self.bottleneck = _DoubleConvParams(features[-1], features[-1] * 2)
+        for f in reversed(features):
+            self.ups.append(nn.ConvTranspose2d(f * 2, f, kernel_size=2, stride=2))
+            self.ups.append(_DoubleConvParams(f * 2, f))
+        self.final_conv = nn.Conv2d(features[0], out_channels, kernel_size=1)
+
+
 class AdaptorSpec(_Holder):
     """Parameter-free output map; ``kind``/``scale``/``shift`` are consumed by ufm_head_tail."""
 

@@ -264,8 +264,12 @@ class UniFlowMatchClassificationRefinement(UniFlowMatch, PyTorchModelHubMixin):
         assert pretrained_checkpoint_path is None, "Pretrained weights are not supported for now"
         self.use_unet_feature = use_unet_feature
         self.feature_combine_method = feature_combine_method
-        if use_unet_feature:
-            raise NotImplementedError("use_unet_feature=True (UNet fine features, unet_encoder.py) is not built yet")
+        if use_unet_feature:  # ufm.py:816-825 (parameter containers; Engine._unet / ufm_unet_combine compute)
+            if feature_combine_method not in ("conv", "modulate"):
+                raise ValueError(f"feature_combine_method {feature_combine_method!r}: the reference defines 'conv' and 'modulate' (ufm.py:821-825)")
+            self.unet_feature = M.UNetParams(in_channels=3, out_channels=16, features=[64, 128, 256, 512])
+            self.conv1 = nn.Conv2d(32, 32, kernel_size=1, stride=1, padding=0)
+            self.conv2 = nn.Conv2d(32 if feature_combine_method == "conv" else 16, 16, kernel_size=1, stride=1, padding=0)
         self.classification_bias = nn.Parameter(torch.zeros(refinement_range * refinement_range))
         if len(uncertainty_head_kwargs) > 0:
             assert uncertainty_head_type == "dpt", "Only DPT is supported for uncertainty head now"
