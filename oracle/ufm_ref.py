@@ -353,7 +353,7 @@ class UFMRef(nn.Module):
             self.classification_bias = nn.Parameter(torch.zeros(refinement_range * refinement_range))
 
     @torch.no_grad()
-    def forward(self, img1: torch.Tensor, img2: torch.Tensor) -> Out:
+    def forward(self, img1: torch.Tensor, img2: torch.Tensor, symmetrized: bool = False) -> Out:
         """ufm.py:562-662 / :843-1009 with symmetrized=False; pure fp32 (the reference's CPU
         path is fp32: its autocast targets "cuda" only, base.py:273)."""
         if img1.shape[-2:] != img2.shape[-2:]:
@@ -363,9 +363,16 @@ class UFMRef(nn.Module):
         # (base.py:273), heads and refinement in the fp32 island (ufm.py:635).  Used only to measure how far the
         # reference's OWN bf16 policy moves the outputs (tests/test_model_gpu.py); the default is the fp32 CPU path.
         with torch.autocast("cpu", dtype=torch.bfloat16, enabled=bool(getattr(self, "autocast_bf16", False))):
-            enc = self.encoder(U.ViTEncoderInput(image=torch.cat((img1, img2), dim=0), data_norm_type=self.encoder.data_norm_type))
-            f1 = [e.features.chunk(2, dim=0)[0] for e in enc]
-            f2 = [e.features.chunk(2, dim=0)[1] for e in enc]
+            if symmetrized:  # ufm.py:336-352: pairs (a,b),(b,a): encode a's and b's once, interleave (ufm.py:69-82)
+                enc = self.encoder(U.ViTEncoderInput(image=torch.cat((img1[::2], img2[::2]), dim=0), data_norm_type=self.encoder.data_norm_type))
+                fa = [e.features.chunk(2, dim=0)[0] for e in enc]
+                fb = [e.features.chunk(2, dim=0)[1] for e in enc]
+                f1 = [torch.stack((a, b), dim=1).flatten(0, 1) for a, b in zip(fa, fb)]
+                f2 = [torch.stack((b, a), dim=1).flatten(0, 1) for a, b in zip(fa, fb)]
+            else:
+                enc = self.encoder(U.ViTEncoderInput(image=torch.cat((img1, img2), dim=0), data_norm_type=self.encoder.data_norm_type))
+                f1 = [e.features.chunk(2, dim=0)[0] for e in enc]
+                f2 = [e.features.chunk(2, dim=0)[1] for e in enc]
             final, inter = self.info_sharing(U.MultiViewTransformerInput(features=[f1[-1], f2[-1]]))
         # ufm.py:602-608: only the view-1 pyramid is ever decoded (:637-641, :698-700)
         pyr1 = [f1[-1].float(), inter[0].features[0].float(), inter[1].features[0].float(), final.features[0].float()]

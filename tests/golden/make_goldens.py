@@ -236,6 +236,26 @@ def main():
         arrays.update(src2=np_(src2), tgt2=np_(tgt2), flow2=np_(out2.flow.flow_output), mask2=np_(out2.covisibility.mask))
         save(f"wiring_{name}.npz", **arrays)
 
+    # -------------------------------------------------- symmetrized encoding
+    # ufm.py:336-352: with symmetrized=True only img1[::2] / img2[::2] are encoded and the features interleaved.  Inputs
+    # here are deliberately NOT symmetric, so the golden pins which image's features end up in which pair and view.
+    for name, refine in [("confidence", False), ("refine", True)]:
+        cfg = R.ufm_tiny_config(refine=refine)
+        ref_cls = ref_ufm.UniFlowMatchClassificationRefinement if refine else ref_ufm.UniFlowMatchConfidence
+        kw = dict(cfg)
+        if refine:
+            kw["classification_head_type"] = "patch_mlp"
+        model = ref_cls(**kw).eval()
+        R.init_weights_(model, seed=3)
+        g = torch.Generator().manual_seed(29)
+        a, b = torch.randn(4, 3, 56, 56, generator=g), torch.randn(4, 3, 56, 56, generator=g)
+        with torch.no_grad():
+            out = model(dict(img=a, symmetrized=True, data_norm_type="dinov2"), dict(img=b, symmetrized=True, data_norm_type="dinov2"))
+        arrays = dict(img1=np_(a), img2=np_(b), seed=np.array(3), flow=np_(out.flow.flow_output), mask=np_(out.covisibility.mask))
+        if refine:
+            arrays["feature_map_1"] = np_(out.classification_refinement.feature_map_1)
+        save(f"wiring_symmetrized_{name}.npz", **arrays)
+
     # ----------------------------------------------------------------- UNet
     # models/unet_encoder.py loads standalone: the reference's OWN class, seeded weights (R.init_weights_), odd sizes that
     # exercise the nearest fix-up at :66-67 (54 -> 27 -> 13 -> 6; 13 vs 2*6, 27 vs 2*13)

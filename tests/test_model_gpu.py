@@ -549,3 +549,32 @@ def test_config4_variant_refine_with_unet_full_size(env):
     df2, dm2, _ = compare(o, pf)
     print(f"UFM-Refine + UNet 518 fast mode: flow max-abs {df2:.3g} px, mask {dm2:.3g}")
     assert df2 <= 0.03 * mx and dm2 <= 0.02, (df2, dm2, mx)
+
+
+@pytest.mark.parametrize("name,refine", [("confidence", False), ("refine", True)])
+def test_symmetrized_forward_against_reference_golden(env, golden_dir, name, refine):
+    """(f)4: forward(view1, view2) with symmetrized=True (ufm.py:336-352): only img1[::2] / img2[::2] are encoded and the
+    features interleaved.  Golden = the reference's real forward on deliberately NON-symmetric inputs (pins which image
+    feeds which pair and view); on genuinely symmetrized inputs the shortcut must equal the plain path bit for bit."""
+    ufm_amd, R = env
+    g = np.load(os.path.join(golden_dir, f"wiring_symmetrized_{name}.npz"))
+    _, prod = build_pair(env, refine=refine, seed=int(g["seed"]))
+    prod.set_numerics("parity")
+    v = lambda t, s: {"img": t.to(DEV), "symmetrized": s, "data_norm_type": "dinov2"}  # noqa: E731
+    a, b = torch.from_numpy(g["img1"]), torch.from_numpy(g["img2"])
+    out = prod(v(a, True), v(b, True))
+    assert np.abs(out.flow.flow_output.cpu().numpy() - g["flow"]).max() <= 1e-3
+    assert np.abs(out.covisibility.mask.cpu().numpy() - g["mask"]).max() <= 1e-3
+    if refine:
+        fm = out.classification_refinement.feature_map_1.cpu().numpy()
+        assert np.abs(fm - g["feature_map_1"]).max() <= 1e-3 * max(1.0, float(np.abs(g["feature_map_1"]).max()))
+    # genuinely symmetrized batch: (a0,b0),(b0,a0),(a1,b1),(b1,a1)
+    s1 = torch.stack([a[0], b[0], a[1], b[1]])
+    s2 = torch.stack([b[0], a[0], b[1], a[1]])
+    for mode in ("parity", "fast"):
+        prod.set_numerics(mode)
+        sym = prod(v(s1, True), v(s2, True)).flow.flow_output.clone()
+        plain = prod(v(s1, False), v(s2, False)).flow.flow_output.clone()
+        assert torch.equal(sym, plain), mode
+    with pytest.raises(ValueError, match="even number"):
+        prod(v(a[:3], True), v(b[:3], True))

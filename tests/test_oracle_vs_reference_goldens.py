@@ -166,3 +166,19 @@ def test_refine_with_unet_wiring_is_pinned(golden_dir, method):
     low = m.forward(s_n, t_n)
     assert np.abs(low.classification_refinement.feature_map_0.numpy() - g["feature_map_0"]).max() <= 1e-4 * max(1.0, float(np.abs(g["feature_map_0"]).max()))
     assert np.abs(low.classification_refinement.residual.numpy() - g["residual"]).max() <= 2e-4
+
+
+@pytest.mark.parametrize("name,refine", [("confidence", False), ("refine", True)])
+def test_symmetrized_encoding_is_pinned(golden_dir, name, refine):
+    """ufm.py:336-352 + interleave (ufm.py:69-82) through the reference's real forward with symmetrized=True on
+    NON-symmetric inputs: pins which image's features land in which pair and view."""
+    g = _load(golden_dir, f"wiring_symmetrized_{name}.npz")
+    m = R.UFMRef(**R.ufm_tiny_config(refine=refine)).eval()
+    R.init_weights_(m, seed=int(g["seed"]))
+    out = m.forward(torch.from_numpy(g["img1"]), torch.from_numpy(g["img2"]), symmetrized=True)
+    assert np.abs(out.flow.flow_output.numpy() - g["flow"]).max() <= 2e-4
+    assert np.abs(out.covisibility.mask.numpy() - g["mask"]).max() <= 1e-5
+    if refine:
+        assert np.abs(out.classification_refinement.feature_map_1.numpy() - g["feature_map_1"]).max() <= 1e-4 * max(1.0, float(np.abs(g["feature_map_1"]).max()))
+    plain = m.forward(torch.from_numpy(g["img1"]), torch.from_numpy(g["img2"]), symmetrized=False)
+    assert (plain.flow.flow_output - out.flow.flow_output).abs().max() > 1e-2  # the golden does exercise the interleave

@@ -257,16 +257,24 @@ class Engine:
             self._tables[key] = (cls0.to(self.dev), patch[0].contiguous().to(self.dev))
         return self._tables[key]
 
-    def _index_tables(self, B: int, Np: int):
-        key = ("idx", B, Np)
+    def _index_tables(self, B: int, Np: int, symmetrized: bool = False):
+        key = ("idx", B, Np, symmetrized)
         if key not in self._tables:
             N = Np + 1
             p = torch.arange(Np)
             b = torch.arange(B).view(B, 1)
-            v1 = (b * N + 1 + p).reshape(-1)  # view-1 patch rows of the encoder buffer
-            all_ = (torch.arange(2 * B).view(-1, 1) * N + 1 + p).reshape(-1)
-            v = torch.arange(2).view(1, 2, 1)
-            info = ((v * B + b.view(B, 1, 1)) * N + 1 + p.view(1, 1, Np)).reshape(-1)  # (pair, view, patch) order
+            if symmetrized:
+                # ufm.py:336-352: the encoder buffer holds B images = [img1[::2] | img2[::2]] = [a_0.. | b_0..]; pair 2i is
+                # (a_i, b_i), pair 2i+1 is (b_i, a_i) (interleave, ufm.py:69-82)
+                half = B // 2
+                i, odd = torch.arange(B) // 2, torch.arange(B) % 2
+                img_v1 = torch.where(odd == 0, i, half + i)  # encoder image that is view 1 of pair p
+                img_v2 = torch.where(odd == 0, half + i, i)
+            else:
+                img_v1, img_v2 = torch.arange(B), B + torch.arange(B)  # images ordered [view-1 batch | view-2 batch] (ufm.py:308)
+            v1 = (img_v1.view(B, 1) * N + 1 + p).reshape(-1)  # view-1 patch rows of the encoder buffer
+            all_ = (torch.cat([img_v1, img_v2]).view(-1, 1) * N + 1 + p).reshape(-1)
+            info = (torch.stack([img_v1, img_v2], dim=1).view(B, 2, 1) * N + 1 + p.view(1, 1, Np)).reshape(-1)  # (pair, view, patch) order
             iv1 = (b * 2 * Np + p).reshape(-1)
             iv2 = (b * 2 * Np + Np + p).reshape(-1)
             mk = lambda t: t.to(torch.int32).to(self.dev)  # noqa: E731
@@ -470,7 +478,7 @@ class Engine:
 
     # ------------------------------------------------------------------ full forward
     @torch.no_grad()
-    def forward(self, src, tgt, *, layout: int, scale3, shift3, H: int, W: int, Hs: int, Ws: int, Ht: int, Wt: int) -> Dict[str, Any]:
+    def forward(self, src, tgt, *, layout: int, scale3, shift3, H: int, W: int, Hs: int, Ws: int, Ht: int, Wt: int, symmetrized: bool = False) -> Dict[str, Any]:
         """src/tgt: device images (uint8 or float32, BHWC layout=0 / BCHW layout=1) of sizes
         (Hs,Ws)/(Ht,Wt); (H,W) is the network resolution.  Returns network-resolution outputs.
 
@@ -481,10 +489,12 @@ class Engine:
         depend on its batch neighbours)."""
         self._pack()
         B = src.shape[0]
-        nmb = self.micro_batches if (B >= 2 * self.micro_batches and hip.TIMER is None) else 1
+        if symmetrized and (B % 2 != 0 or (Hs, Ws) != (Ht, Wt)):
+            raise ValueError("symmetrized=True needs an even number of equally sized pairs: (a,b),(b,a),... (ufm.py:336-352)")
+        nmb = self.micro_batches if (B >= 2 * self.micro_batches and hip.TIMER is None and not symmetrized) else 1
         if nmb == 1:
             self._tls.ns = ""
-            return self._forward_images(src, tgt, layout, scale3, shift3, H, W, Hs, Ws, Ht, Wt)
+            return self._forward_images(src, tgt, layout, scale3, shift3, H, W, Hs, Ws, Ht, Wt, symmetrized)
         bounds = [(i * B) // nmb for i in range(nmb + 1)]
         gh, gw = H // self.P, W // self.P
         self._pos_tables(H, W)  # shared read-only tables are built here, before the workers start
@@ -545,21 +555,26 @@ class Engine:
                 out[tag] = {name: {k: cat([p[tag][name][k] for p in parts]) for k in parts[0][tag][name]} for name in parts[0][tag]}
         return out
 
-    def _forward_images(self, src, tgt, layout, scale3, shift3, H, W, Hs, Ws, Ht, Wt) -> Dict[str, Any]:
+    def _forward_images(self, src, tgt, layout, scale3, shift3, H, W, Hs, Ws, Ht, Wt, symmetrized: bool = False) -> Dict[str, Any]:
         B = src.shape[0]
-        B2 = 2 * B
         gh, gw = H // self.P, W // self.P
         Np = gh * gw
-        patches = self.buf("patches", (B2 * Np, KPAD), self.adt)
+        # symmetrized (ufm.py:345-347): only img1[::2] / img2[::2] are encoded; everything after the encoder sees all B pairs
+        enc_views = ((src[::2].contiguous(), Hs, Ws), (tgt[::2].contiguous(), Ht, Wt)) if symmetrized else ((src, Hs, Ws), (tgt, Ht, Wt))
+        Be = enc_views[0][0].shape[0]
+        if symmetrized and (Hs, Ws) != (H, W):
+            raise NotImplementedError("symmetrized=True is the lower-level forward() path: images arrive at network resolution")
+        patches = self.buf("patches", (2 * Be * Np, KPAD), self.adt)
         want_unet = self.refine and self.unet is not None
         # view["img"] of ufm.py:915-917 per view: normalised, network resolution, NHWC with 3 -> 32 zero-padded channels
         unet_imgs = [self.hbuf(f"un_img{v}", (B, H, W, 32)) for v in range(2)] if want_unet else None
-        for v, (img, h0, w0) in enumerate(((src, Hs, Ws), (tgt, Ht, Wt))):
-            dst = patches[v * B * Np : (v + 1) * B * Np]
+        for v, (img, h0, w0) in enumerate(enc_views):
+            dst = patches[v * Be * Np : (v + 1) * Be * Np]
+            full = (src, tgt)[v]
             if (h0, w0) == (H, W):
-                hip.patchify(img, layout, B, H, W, self.P, scale3, shift3, dst, KPAD)
+                hip.patchify(img, layout, Be, H, W, self.P, scale3, shift3, dst, KPAD)
                 if want_unet:
-                    hip.image_to_nhwc(img, layout, B, H, W, scale3, shift3, unet_imgs[v], 32)
+                    hip.image_to_nhwc(full, layout, B, H, W, scale3, shift3, unet_imgs[v], 32)
             else:  # normalise-on-load + separable antialias resize (flow_resizing.py:313-326), then patchify
                 rs = self.buf(f"resized{v}", (B, 3, H, W))
                 tmp = self.buf(f"resize_tmp{v}", (B * 3 * h0 * W,))
@@ -567,13 +582,14 @@ class Engine:
                 hip.patchify(rs, 1, B, H, W, self.P, [1.0, 1.0, 1.0], [0.0, 0.0, 0.0], dst, KPAD)
                 if want_unet:
                     hip.image_to_nhwc(rs, 1, B, H, W, [1.0, 1.0, 1.0], [0.0, 0.0, 0.0], unet_imgs[v], 32)
-        return self._forward_patches(patches, B, H, W, unet_imgs)
+        return self._forward_patches(patches, B, H, W, unet_imgs, symmetrized)
 
-    def _forward_patches(self, patches, B: int, H: int, W: int, unet_imgs: Optional[List[torch.Tensor]] = None) -> Dict[str, Any]:
+    def _forward_patches(self, patches, B: int, H: int, W: int, unet_imgs: Optional[List[torch.Tensor]] = None, symmetrized: bool = False) -> Dict[str, Any]:
         B2 = 2 * B
         gh, gw = H // self.P, W // self.P
-        x, Np, N = self._encode(patches, B2, H, W)
-        idx = self._index_tables(B, Np)
+        n_enc = B if symmetrized else B2  # images that go through the encoder
+        x, Np, N = self._encode(patches, n_enc, H, W)
+        idx = self._index_tables(B, Np, symmetrized)
         D, Di = self.D, self.Di
         nw, nb = self.enc_norm
         enc_first = None
@@ -591,7 +607,7 @@ class Engine:
                 lvl0 = self.level_ln(xx, D, idx["enc_v1"], B * Np, nw, nb, "lvl0")
 
         blocks = self.enc_blocks[: self.enc_indices[-1] + 1]  # blocks past the last returned index never matter
-        self._blocks(blocks, x, B2, N, D, self.enc_heads, on_enc)
+        self._blocks(blocks, x, n_enc, N, D, self.enc_heads, on_enc)
 
         # ---- info sharing: joint attention over the 2*Np tokens of each pair ----
         M2 = B * 2 * Np

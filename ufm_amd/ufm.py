@@ -120,8 +120,6 @@ class UniFlowMatch(UniFlowMatchModelsBase, PyTorchModelHubMixin):
     # ------------------------------------------------------------------ forward
     def _check_views(self, view1, view2):
         img1, img2 = view1["img"], view2["img"]
-        if view1.get("symmetrized", False):
-            raise NotImplementedError("symmetrized=True is a training-time shortcut (ufm.py:338-350); not built")
         if img1.shape[-2:] != img2.shape[-2:]:
             raise NotImplementedError("Unequal Image sizes are not supported now")  # ufm.py:316-317
         want = self.encoder.data_norm_type
@@ -137,11 +135,13 @@ class UniFlowMatch(UniFlowMatchModelsBase, PyTorchModelHubMixin):
         if not img1.is_cuda:
             raise RuntimeError("ufm_amd runs on an AMD GPU only (no CPU fallback)")
         H, W = int(img1.shape[2]), int(img1.shape[3])
+        # symmetrized (ufm.py:336-352): pairs come as (a,b),(b,a): a's and b's are encoded once and the features interleaved
+        sym = bool(view1.get("symmetrized", False))
         with torch.cuda.device(img1.device):
-            return self._forward_device(img1.contiguous(), img2.contiguous(), 1, [1.0] * 3, [0.0] * 3, H, W, H, W, H, W)
+            return self._forward_device(img1.contiguous(), img2.contiguous(), 1, [1.0] * 3, [0.0] * 3, H, W, H, W, H, W, symmetrized=sym)
 
-    def _forward_device(self, src, tgt, layout, scale3, shift3, H, W, hs, ws, ht, wt) -> UFMOutputInterface:
-        raw = self.engine().forward(src, tgt, layout=layout, scale3=scale3, shift3=shift3, H=H, W=W, Hs=hs, Ws=ws, Ht=ht, Wt=wt)
+    def _forward_device(self, src, tgt, layout, scale3, shift3, H, W, hs, ws, ht, wt, symmetrized: bool = False) -> UFMOutputInterface:
+        raw = self.engine().forward(src, tgt, layout=layout, scale3=scale3, shift3=shift3, H=H, W=W, Hs=hs, Ws=ws, Ht=ht, Wt=wt, symmetrized=symmetrized)
         return self._package(raw)
 
     def _package(self, raw: Dict[str, Any]) -> UFMOutputInterface:
