@@ -93,11 +93,16 @@ int ufm_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M,
                   int res_row_mod, void* out, int out_dtype, int ldo, int out_row_group,
                   void* stream);
 
-/* Tuning hook: force_small=1 pins ufm_gemm_bf16 to its 128x128 kernel (A/B timing in one process). */
-int ufm_debug_set_gemm_variant(int force_small);
-/* Tuning hook (timing diagnostics only; 0 = normal). */
+/* Tuning hooks (tests / tools only; the product path never calls them).
+ * variant: 0 = auto (cost model per shape), 1 = 128x128 kernel, 4 = 256x256 8-phase kernel, 5 = hybrid (8-phase on the rows
+ * that fill whole rounds of the chip + 128x128 on the rest).  flags (timing diagnostics, results are wrong): 2 = no DMA,
+ * 4 = no epilogue traffic, 8 = direct (un-staged) epilogue of the 128x128 kernel (results right). */
+int ufm_debug_set_gemm_variant(int variant);
+int ufm_debug_set_gemm_flags(int flags);
+/* Tuning hook for ufm_attention_bf16 (scale == 0 form): 0 = 4 waves per workgroup (default), 1 = 2 waves per workgroup. */
 int ufm_debug_set_attn_variant(int v);
-/* Tuning hook for ufm_conv2d_nhwc_bf16x3: 0 = auto, 1 = 128-row kernels only, 2 = 256x256 8-phase kernel wherever applicable. */
+/* Tuning hook for ufm_conv2d_nhwc_bf16x3: 0 = auto, 1 = 128-row kernels only, 2 = 256x256 8-phase kernel wherever applicable,
+ * 3 = 128-row kernels only and never the deep (4-stage) ring. */
 int ufm_debug_set_conv_variant(int v);
 /* Tuning hook for ufm_upsample_bilinear_nhwc (split format): 1 = LDS-tiled kernel where applicable (default), 0 = never. */
 int ufm_debug_set_upsample_variant(int tiled);

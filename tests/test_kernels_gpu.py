@@ -133,12 +133,13 @@ def test_gemm_gelu_epilogue_accuracy(hip, variant):
     assert (got.float() - want.float())[~fit].abs().max().item() <= 2e-8
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 28])
+@pytest.mark.parametrize("variant,flags", [(1, 0), (4, 0), (5, 0), (1, 8)])
 @pytest.mark.parametrize("M,N,K,out_bf16", [(256 * 70 + 13, 768, 192, True), (256 * 64 + 200, 1024, 640, False)])
-def test_gemm_large_tile_variants(hip, variant, M, N, K, out_bf16):
-    """All three tile shapes (128x128 / 256x128 3-stage / 256x256 4-stage ring) against the same fp64 statement,
-    ragged M, short and long K (prologue/epilogue of the DMA ring)."""
+def test_gemm_large_tile_variants(hip, variant, flags, M, N, K, out_bf16):
+    """Every kernel choice of ufm_gemm_bf16 (128x128, 256x256 8-phase, hybrid split; flags 8 = the 128x128 kernel's direct
+    epilogue) against the same fp64 statement, ragged M, short and long K (prologue/epilogue of the DMA ring)."""
     lib = hip.lib()
+    lib.ufm_debug_set_gemm_flags(flags)
     A = bf16r(rnd(M, K, seed=1))
     W = bf16r(rnd(N, K, seed=2, scale=K**-0.5))
     bias, gamma, res = rnd(N, seed=3, scale=0.1), 1 + rnd(N, seed=4, scale=0.1), rnd(M, N, seed=5)
@@ -149,8 +150,10 @@ def test_gemm_large_tile_variants(hip, variant, M, N, K, out_bf16):
         hip.gemm_bf16(A.to(DEV).bfloat16(), W.to(DEV).bfloat16(), M, N, K, out, bias=bias.to(DEV), gamma=gamma.to(DEV), res=res.to(DEV))
     finally:
         lib.ufm_debug_set_gemm_variant(0)
+        lib.ufm_debug_set_gemm_flags(0)
     err = (out.float().cpu().double() - ref).abs().max().item()
     assert err <= (3e-2 if out_bf16 else 3e-4) * max(1.0, ref.abs().max().item()), err
+    assert lib.ufm_debug_set_gemm_variant(3) != 0  # retired variants are rejected, not silently mapped
 
 
 def test_gemm_in_place_residual(hip):
@@ -201,10 +204,10 @@ def test_attention_bf16(hip, B, N, H):
 
 
 @pytest.mark.parametrize("B,N,H", [(1, 17, 1), (2, 100, 2), (2, 1370, 2), (1, 2738, 3), (1, 64, 1), (1, 129, 1)])
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1])
 def test_attention_bf16_prescaled_log2_kernel(hip, B, N, H, variant):
     """scale == 0 path: Q columns pre-multiplied by scale*log2(e) (what the QKV GEMM epilogue does).
-    variant 0 = 64-rows-per-wave kernel, 4 waves (default), 1 = same with 2 waves per workgroup, 2 = the round-1 kernel."""
+    variant 0 = 64-rows-per-wave kernel with 4 waves per workgroup (default), 1 = the same with 2 waves per workgroup."""
     hip.lib().ufm_debug_set_attn_variant(variant)
     qkv = rnd(B * N, 3 * H * 64, seed=N, scale=1.5)
     qkv_b = bf16r(qkv)
@@ -222,7 +225,7 @@ def test_attention_bf16_prescaled_log2_kernel(hip, B, N, H, variant):
     assert err <= 3e-2, err  # + one extra bf16 rounding of the already-rounded test Q (not present in the fused pipeline)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("growth", [3.0, 30.0])
 def test_attention_bf16_prescaled_deferred_rescale_branches(hip, growth, variant):
     """Late keys whose scores exceed the running reference by less / more than the deferral threshold (rule 26):
@@ -276,13 +279,15 @@ def test_attention_bf16_pw_reference_moves(hip, growth, variant):
 @pytest.mark.parametrize("variant", [0, 1])
 def test_attention_bf16_pw_repeatable_full_size(hip, variant):
     """Race screen for the LDS-DMA ring (counted waits + one barrier per key tile): UFM-Base shapes, repeated launches
-    must agree bit for bit, and with the round-1 kernel to bf16 rounding."""
+    must agree bit for bit, and with the independent scale > 0 kernel (un-scaled Q) to bf16 rounding."""
     lib = hip.lib()
     for B, N, H in ((2, 1370, 16), (1, 2738, 12)):
-        qkv = (rnd(B * N, 3 * H * 64, seed=N, scale=1.0)).to(DEV).bfloat16()
-        lib.ufm_debug_set_attn_variant(2)
+        raw = rnd(B * N, 3 * H * 64, seed=N, scale=1.0)
         want = torch.zeros(B * N, H * 64, device=DEV, dtype=torch.bfloat16)
-        hip.attention(qkv, want, B, N, H, 0.0)
+        hip.attention(raw.to(DEV).bfloat16(), want, B, N, H, 0.125)
+        pre = raw.clone()
+        pre[:, : H * 64] = bf16r(raw[:, : H * 64]) * (0.125 * 1.4426950408889634)
+        qkv = pre.to(DEV).bfloat16()
         lib.ufm_debug_set_attn_variant(variant)
         try:
             first = None
@@ -291,7 +296,7 @@ def test_attention_bf16_pw_repeatable_full_size(hip, variant):
                 hip.attention(qkv, got, B, N, H, 0.0)
                 if first is None:
                     first = got.clone()
-                    assert (got.float() - want.float()).abs().max().item() <= 4e-2  # 1 bf16 ulp at |O| ~ 4
+                    assert (got.float() - want.float()).abs().max().item() <= 6e-2  # bf16 ulps at |O| ~ 4 + the second rounding of Q
                 assert torch.equal(got.view(torch.int16), first.view(torch.int16)), rep
         finally:
             lib.ufm_debug_set_attn_variant(0)

@@ -4,7 +4,13 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ufm_amd import hip
 lib = hip.lib()
+# variant codes: 0 auto, 1 = 128x128, 4 = 8-phase, 5 = hybrid; +40 = the same with flags 4 (no epilogue traffic: main loop only)
 variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["1", "4"])]
+
+
+def set_variant(v):
+    lib.ufm_debug_set_gemm_flags(4 if v >= 40 else 0)
+    lib.ufm_debug_set_gemm_variant(v - 40 if v >= 40 else v)
 shapes = [(4096, 4096, 4096, "bf16"), (8192, 8192, 8192, "bf16"), (21904, 3072, 128, "bf16"), (21904, 3072, 128, "f32"), (21904, 3072, 256, "bf16"), (21904, 1024, 128, "res"), (21904, 1024, 128, "f32"),
           (21904, 3072, 1024, "bf16"), (21904, 1024, 1024, "res"), (21904, 4096, 1024, "gelu"), (21904, 1024, 4096, "res"),
           (10952, 3072, 1024, "bf16"), (10952, 1024, 1024, "res"), (10952, 4096, 1024, "gelu"), (10952, 1024, 4096, "res"),
@@ -19,7 +25,7 @@ for M, N, K, mode in shapes:
     times = {v: [] for v in variants}
     for rnd in range(7):
         for v in variants:
-            lib.ufm_debug_set_gemm_variant(v)
+            set_variant(v)
             run(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -27,7 +33,7 @@ for M, N, K, mode in shapes:
                 run()
             e1.record(); torch.cuda.synchronize()
             times[v].append(e0.elapsed_time(e1) / 5)
-    lib.ufm_debug_set_gemm_variant(0)
+    set_variant(0)
     msg = f"M={M} N={N} K={K} {mode}: "
     for v in variants:
         t = sorted(times[v]); med = t[len(t) // 2]

@@ -53,7 +53,7 @@ def main():
             gamma = torch.ones(n, device=DEV) if resid else None
             out = torch.randn(m, n, device=DEV) if resid else torch.empty(m, n, device=DEV, dtype=torch.bfloat16)
             row = {}
-            for variant, vname in ((1, "128x128-ldsepi"), (28, "128x128-direct")):
+            for variant, vname in ((0, "auto"), (1, "128x128"), (4, "8-phase")):
                 lib.ufm_debug_set_gemm_variant(variant)
                 med, mn = timeit(lambda: hip.gemm_bf16(A, W, m, n, k, out, bias=bias, act=act, gamma=gamma, res=out if resid else None))
                 row[vname] = dict(ms=med, tflops=2.0 * m * n * k / med / 1e9)
@@ -67,7 +67,7 @@ def main():
             fl = 4.0 * b * h * n * n * 64
             qkv2 = qkv.clone()
             qkv2[:, : h * 64] = (qkv[:, : h * 64].float() * (0.125 * 1.4426950408889634)).bfloat16()
-            for sc, vn, dbg in ((0.0, "pw4", 0), (0.0, "pw2", 1), (0.0, "v2-round1", 2), (0.0, "pw4", 0), (0.0, "pw2", 1), (0.0, "v2-round1", 2)):
+            for sc, vn, dbg in ((0.0, "pw4", 0), (0.0, "pw2", 1), (0.125, "scale>0 kernel", 0), (0.0, "pw4", 0), (0.0, "pw2", 1), (0.125, "scale>0 kernel", 0)):
                 src = qkv if sc else qkv2
                 lib.ufm_debug_set_attn_variant(dbg)
                 med, mn = timeit(lambda: hip.attention(src, out, b, n, h, sc))

@@ -213,475 +213,16 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __res
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// v2: the same tiling with the softmax VALU work cut to ~1 exp + 1 add + 1/2 max3 per score.
-// PMC on v1 showed VALU 66 % / MFMA 34 % busy: at head_dim 64 the softmax, not the matrix pipe,
-// is the limiter.  Changes:
-//   * Q arrives PRE-SCALED by softmax_scale*log2(e) (the QKV GEMM epilogue multiplies its Q columns
-//     before the single bf16 rounding, so there is no extra rounding), scores are in log2 units;
-//   * the running reference -m_ref lives in a 16-register block that is the C operand of the first
-//     QK^T MFMA of every key tile: the accumulator comes out as S - m_ref with no zero-init movs and
-//     no per-score subtract/FMA;
-//   * deferred rescale (T13): O, l and m_ref are only touched when some query's tile maximum exceeds
-//     m_ref by more than DEFER_THR log2 units (wave-uniform branch); P then ranges up to 2^DEFER_THR,
-//     which bf16 (relative precision) and the fp32 accumulators absorb.  The first tile always sets
-//     m_ref to its exact maximum (so later tiles can only grow it and nothing underflows).
-// ---------------------------------------------------------------------------------------------
-constexpr float DEFER_THR = 4.0f;
-
-__global__ __launch_bounds__(256, 2) void attn_bf16_kernel_v2(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
-                                                              int N, int H, int debug) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nqb = (N + QB - 1) / QB;
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int qblk = lid % nqb, head = (lid / nqb) % H, b = lid / (nqb * H);
-    const int ld = 3 * H * 64;
-    const uint16_t* base = qkv + (size_t)b * N * ld + head * 64;
-    const uint16_t* kp = base + H * 64;
-    const uint16_t* vp = base + 2 * H * 64;
-    const int ql = lane & 31, hh = lane >> 5;
-    const int q = qblk * QB + wave * 32 + ql;
-
-    bf16x8 qf[4];
-    {
-        const uint16_t* qr = base + (size_t)min(q, N - 1) * ld + 8 * hh;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qr + 16 * s);
-    }
-    const int srow = tid >> 3, schunk = tid & 7;
-    int k_lds[2], v_lds[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = srow + 32 * i;
-        k_lds[i] = r * 128 + ((schunk ^ ((r >> 1) & 7)) << 4);
-        v_lds[i] = 8192 + r * 128 + ((schunk ^ (((r >> 1) & 1) << 2)) << 4);
-    }
-    u32x4 kreg[2], vreg[2];
-    auto load_tile = [&](int t) {
-        if (debug == 1 && t > 0) return;  // diagnostics: timing without K/V global traffic
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const size_t row = (size_t)min(t * KB + srow + 32 * i, N - 1);
-            kreg[i] = *(const u32x4*)(kp + row * ld + schunk * 8);
-            vreg[i] = *(const u32x4*)(vp + row * ld + schunk * 8);
-        }
-    };
-    auto store_tile = [&](int stage) {
-        char* s = smem + stage * STAGE;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *(u32x4*)(s + k_lds[i]) = kreg[i];
-            *(u32x4*)(s + v_lds[i]) = vreg[i];
-        }
-    };
-    int k_off[2][4];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int key = kt * 32 + ql;
-            k_off[kt][s] = key * 128 + (((2 * s + hh) ^ ((key >> 1) & 7)) << 4);
-        }
-    const int ti = lane & 15, tq = ti >> 2, tp = ti & 3;
-    const int tdc = 16 * ((lane >> 4) & 1) + 4 * tp;
-    int v_off[2][2][2][2];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int row = kt * 32 + 16 * s2 + 4 * hh + 8 * e + tq;
-                    const int dcol = dt * 32 + tdc;
-                    v_off[dt][kt][s2][e] = 8192 + row * 128 + ((((dcol >> 3)) ^ (((row >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1);
-                }
-
-    f32x16 oacc[2], negm;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        oacc[0][r] = 0.f;
-        oacc[1][r] = 0.f;
-        negm[r] = 0.f;
-    }
-    float l_run = 0.f;
-
-    const int nt = (N + KB - 1) / KB;
-    // One key tile.  FIRST / LAST are compile-time so the steady-state body carries neither the
-    // reference initialisation nor the ragged-tail selects (hipcc if-converts run-time versions of
-    // those into straight-line code that executes on every tile).
-    auto tile = [&](int t, auto first_c, auto last_c) {
-        constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
-        if (!LAST) load_tile(t + 1);
-        const char* s = smem + (t & 1) * STAGE;
-
-        // all 8 K fragments in flight at once (one exposed LDS latency instead of eight) ...
-        bf16x8 kf[2][4];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) kf[kt][ks] = *(const bf16x8*)(s + k_off[kt][ks]);
-        __builtin_amdgcn_sched_barrier(0);
-        f32x16 st[2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][0], qf[0], negm, 0, 0, 0);
-#pragma unroll
-            for (int ks = 1; ks < 4; ++ks) st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][ks], qf[ks], st[kt], 0, 0, 0);
-        }
-        // ... and the 16 transposed V reads are issued now, behind the QK^T MFMAs: they land while the
-        // softmax runs, so no P.V MFMA waits on LDS.
-        bf16x4 vlo[2][2][2], vhi[2][2][2];
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    vlo[dt][kt][s2] = tr_read(s + v_off[dt][kt][s2][0]);
-                    vhi[dt][kt][s2] = tr_read(s + v_off[dt][kt][s2][1]);
-                }
-        __builtin_amdgcn_sched_barrier(0);
-        if (LAST) {  // ragged tail: keys >= N
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = t * KB + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    if (key >= N) st[kt][r] = NEG_BIG;
-                }
-        }
-        float mx = fmaxf(st[0][0], st[1][0]);
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(st[0][r], st[1][r]));
-        {
-            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-        }
-        if (FIRST) {  // reference = exact maximum of the first tile (O and l are still zero)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                negm[r] = -mx;
-                st[0][r] -= mx;
-                st[1][r] -= mx;
-            }
-        } else if (__builtin_amdgcn_ballot_w64(mx > DEFER_THR) != 0) {  // rare: move the reference
-            asm volatile("" ::: "memory");  // keep this a real (wave-uniform) branch
-            const float d = fmaxf(mx, 0.f);
-            const float alpha = __builtin_amdgcn_exp2f(-d);
-            l_run *= alpha;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                negm[r] -= d;
-                st[0][r] -= d;
-                st[1][r] -= d;
-                oacc[0][r] *= alpha;
-                oacc[1][r] *= alpha;
-            }
-        }
-        float lsum = 0.f;
-        bf16x8 pf[2][2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            unsigned pk[8];
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const float p0 = __builtin_amdgcn_exp2f(st[kt][r]);
-                const float p1 = __builtin_amdgcn_exp2f(st[kt][r + 1]);
-                lsum += p0;
-                lsum += p1;
-                pk[r >> 1] = pack_bf16x2(p0, p1);
-            }
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                u32x4 w = {pk[4 * s2], pk[4 * s2 + 1], pk[4 * s2 + 2], pk[4 * s2 + 3]};
-                pf[kt][s2] = __builtin_bit_cast(bf16x8, w);
-            }
-        }
-        l_run += lsum;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const bf16x4 lo = vlo[dt][kt][s2], hi = vhi[dt][kt][s2];
-                    const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][s2], oacc[dt], 0, 0, 0);
-                }
-        if (!LAST) store_tile((t + 1) & 1);
-        __syncthreads();
-    };
-    using T_ = std::integral_constant<bool, true>;
-    using F_ = std::integral_constant<bool, false>;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    if (nt == 1) {
-        tile(0, T_{}, T_{});
-    } else {
-        tile(0, T_{}, F_{});
-        for (int t = 1; t < nt - 1; ++t) tile(t, F_{}, F_{});
-        tile(nt - 1, F_{}, T_{});
-    }
-
-    float l_tot;
-    {
-        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
-        l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-    }
-    const float inv = 1.0f / l_tot;
-    if (q < N) {
-        uint16_t* orow = out + ((size_t)b * N + q) * (H * 64) + head * 64 + 4 * hh;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                u32x2 pk = {pack_bf16x2(oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv),
-                            pack_bf16x2(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv)};
-                *(u32x2*)(orow + dt * 32 + 8 * g) = pk;
-            }
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// v3 = v2 + cross-tile software pipelining.  PMC on v2: MFMA busy 36 %, VALU busy 55 %, 35 % of wave
-// time in issue stalls at 2 waves/SIMD -- neither pipe is full because inside one wave the chain
-// QK^T -> max -> exp -> P.V is serial.  Here the QK^T MFMAs of key tile t+1 are issued BEFORE the
-// softmax of tile t (they only need K(t+1) and the current -m_ref), so the matrix pipe runs under the
-// VALU block of the same wave; a rescale event at tile t also shifts the already-computed S(t+1).
-// K/V tiles live in a 3-stage LDS ring (48 KiB): tile t+2 is written while t (V) and t+1 (K) are
-// being read, so there is still one barrier per tile.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_bf16_kernel_v3(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
-                                                              int N, int H) {
-    constexpr int NS = 3;
-    __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nqb = (N + QB - 1) / QB;
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int qblk = lid % nqb, head = (lid / nqb) % H, b = lid / (nqb * H);
-    const int ld = 3 * H * 64;
-    const uint16_t* base = qkv + (size_t)b * N * ld + head * 64;
-    const uint16_t* kp = base + H * 64;
-    const uint16_t* vp = base + 2 * H * 64;
-    const int ql = lane & 31, hh = lane >> 5;
-    const int q = qblk * QB + wave * 32 + ql;
-
-    bf16x8 qf[4];
-    {
-        const uint16_t* qr = base + (size_t)min(q, N - 1) * ld + 8 * hh;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8*)(qr + 16 * s);
-    }
-    const int srow = tid >> 3, schunk = tid & 7;
-    int k_lds[2], v_lds[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = srow + 32 * i;
-        k_lds[i] = r * 128 + ((schunk ^ ((r >> 1) & 7)) << 4);
-        v_lds[i] = 8192 + r * 128 + ((schunk ^ (((r >> 1) & 1) << 2)) << 4);
-    }
-    u32x4 kreg[2], vreg[2];
-    auto load_tile = [&](int t) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const size_t row = (size_t)min(t * KB + srow + 32 * i, N - 1);
-            kreg[i] = *(const u32x4*)(kp + row * ld + schunk * 8);
-            vreg[i] = *(const u32x4*)(vp + row * ld + schunk * 8);
-        }
-    };
-    auto store_tile = [&](int stage) {
-        char* s = smem + stage * STAGE;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *(u32x4*)(s + k_lds[i]) = kreg[i];
-            *(u32x4*)(s + v_lds[i]) = vreg[i];
-        }
-    };
-    int k_off[2][4];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int key = kt * 32 + ql;
-            k_off[kt][s] = key * 128 + (((2 * s + hh) ^ ((key >> 1) & 7)) << 4);
-        }
-    const int ti = lane & 15, tq = ti >> 2, tp = ti & 3;
-    const int tdc = 16 * ((lane >> 4) & 1) + 4 * tp;
-    int v_off[2][2][2][2];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int row = kt * 32 + 16 * s2 + 4 * hh + 8 * e + tq;
-                    const int dcol = dt * 32 + tdc;
-                    v_off[dt][kt][s2][e] = 8192 + row * 128 + ((((dcol >> 3)) ^ (((row >> 1) & 1) << 2)) << 4) + ((dcol & 7) << 1);
-                }
-
-    f32x16 oacc[2], negm;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        oacc[0][r] = 0.f;
-        oacc[1][r] = 0.f;
-        negm[r] = 0.f;
-    }
-    float l_run = 0.f;
-    const int nt = (N + KB - 1) / KB;
-
-    // S^T(t) - m_ref for key tile t (stage t % NS); MASK: ragged tail of the last tile
-    auto qk = [&](f32x16 (&st)[2], int t, auto mask_c) {
-        constexpr bool MASK = decltype(mask_c)::value;
-        const char* s = smem + (t % NS) * STAGE;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            bf16x8 kf[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const bf16x8*)(s + k_off[kt][ks]);
-            st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], negm, 0, 0, 0);
-#pragma unroll
-            for (int ks = 1; ks < 4; ++ks) st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], st[kt], 0, 0, 0);
-        }
-        if (MASK) {
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = t * KB + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    if (key >= N) st[kt][r] = NEG_BIG;
-                }
-        }
-    };
-    using T_ = std::integral_constant<bool, true>;
-    using F_ = std::integral_constant<bool, false>;
-
-    // ---- prologue: tiles 0 and 1 into the ring, S(0), tile 2 into registers ----
-    load_tile(0);
-    store_tile(0);
-    if (nt > 1) {
-        load_tile(1);
-        store_tile(1);
-    }
-    __syncthreads();
-    if (nt > 2) load_tile(2);
-    f32x16 sa[2], sb[2];  // S of the current / next tile (two named sets, swapped by unrolling x2)
-    if (nt == 1) qk(sa, 0, T_{}); else qk(sa, 0, F_{});
-
-    // one pipeline step: softmax + P.V of tile t from `cur`, QK^T of tile t+1 into `nxt`
-    auto step = [&](f32x16 (&cur)[2], f32x16 (&nxt)[2], int t) {
-        if (t + 2 < nt) {  // registers hold tile t+2 (loaded one step ago): park it, fetch t+3
-            store_tile((t + 2) % NS);
-            if (t + 3 < nt) load_tile(t + 3);
-        }
-        const bool has_next = t + 1 < nt;
-        if (has_next) {
-            if (t + 2 == nt) qk(nxt, t + 1, T_{}); else qk(nxt, t + 1, F_{});
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const char* s = smem + (t % NS) * STAGE;
-        // ---- softmax of tile t (runs on the VALU while the QK^T MFMAs above execute) ----
-        float mx = fmaxf(cur[0][0], cur[1][0]);
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(cur[0][r], cur[1][r]));
-        {
-            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-        }
-        if (t == 0 || __builtin_amdgcn_ballot_w64(mx > DEFER_THR) != 0) {  // first tile / rare: move the reference
-            asm volatile("" ::: "memory");
-            const float d = (t == 0) ? mx : fmaxf(mx, 0.f);
-            const float alpha = (t == 0) ? 1.0f : __builtin_amdgcn_exp2f(-d);
-            l_run *= alpha;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                negm[r] -= d;
-                cur[0][r] -= d;
-                cur[1][r] -= d;
-                nxt[0][r] -= d;  // S(t+1) was formed against the old reference
-                nxt[1][r] -= d;
-                oacc[0][r] *= alpha;
-                oacc[1][r] *= alpha;
-            }
-        }
-        float lsum = 0.f;
-        bf16x8 pf[2][2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            unsigned pk[8];
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const float p0 = __builtin_amdgcn_exp2f(cur[kt][r]);
-                const float p1 = __builtin_amdgcn_exp2f(cur[kt][r + 1]);
-                lsum += p0;
-                lsum += p1;
-                pk[r >> 1] = pack_bf16x2(p0, p1);
-            }
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                u32x4 w = {pk[4 * s2], pk[4 * s2 + 1], pk[4 * s2 + 2], pk[4 * s2 + 3]};
-                pf[kt][s2] = __builtin_bit_cast(bf16x8, w);
-            }
-        }
-        l_run += lsum;
-        // ---- O^T += V^T . P^T for tile t ----
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            bf16x4 vlo[2][2], vhi[2][2];
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    vlo[kt][s2] = tr_read(s + v_off[dt][kt][s2][0]);
-                    vhi[kt][s2] = tr_read(s + v_off[dt][kt][s2][1]);
-                }
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const bf16x4 lo = vlo[kt][s2], hi = vhi[kt][s2];
-                    const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][s2], oacc[dt], 0, 0, 0);
-                }
-        }
-        __syncthreads();  // tile t+2 visible; stage t % NS free for tile t+3
-    };
-    for (int t = 0; t < nt; t += 2) {
-        step(sa, sb, t);
-        if (t + 1 < nt) step(sb, sa, t + 1);
-    }
-
-    float l_tot;
-    {
-        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
-        l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-    }
-    const float inv = 1.0f / l_tot;
-    if (q < N) {
-        uint16_t* orow = out + ((size_t)b * N + q) * (H * 64) + head * 64 + 4 * hh;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                u32x2 pk = {pack_bf16x2(oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv),
-                            pack_bf16x2(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv)};
-                *(u32x2*)(orow + dt * 32 + 8 * g) = pk;
-            }
-    }
-}
-
 }  // namespace
 
 int ufm_launch_attn_pw(const uint16_t* qkv, uint16_t* out, int B, int N, int H, int variant, hipStream_t stream);  // attention_bf16_pw.hip
 
 static int g_attn_debug = 0;
-extern "C" int ufm_debug_set_attn_variant(int v) {
+extern "C" int ufm_debug_set_attn_variant(int v) {  // 0 = 4 waves per workgroup (default), 1 = 2 waves per workgroup
+    if (v != 0 && v != 1) {
+        ufm_set_error("ufm_debug_set_attn_variant: %d is not 0 (4 waves) or 1 (2 waves)", v);
+        return UFM_ERR_ARG;
+    }
     g_attn_debug = v;
     return UFM_OK;
 }
@@ -691,13 +232,8 @@ extern "C" int ufm_attention_bf16(const uint16_t* qkv, uint16_t* out, int B, int
     UFM_REQUIRE(B > 0 && N > 0 && H > 0 && (int64_t)((N + QB - 1) / QB) * H * B < (1ll << 31), "ufm_attention_bf16: bad shape B=%d N=%d H=%d", B, N, H);
     UFM_REQUIRE(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 8) == 0, "ufm_attention_bf16: misaligned pointer");
     dim3 grid(((N + QB - 1) / QB) * H * B), block(256);
-    if (scale == 0.0f && (g_attn_debug == 0 || g_attn_debug == 1))  // default: 64 rows per wave, one wave per SIMD (0: 4 waves, 1: 2 waves per workgroup)
+    if (scale == 0.0f)  // Q pre-scaled by softmax_scale*log2(e): 64 rows per wave, one wave per SIMD (attention_bf16_pw.hip)
         ufm_launch_attn_pw(qkv, out, B, N, H, g_attn_debug, (hipStream_t)stream);
-    else if (scale == 0.0f && g_attn_debug == 3)  // opt-in: cross-tile pipelined v3 (+3..10 % on randn data in tools/kbench.py,
-                                             // but 26 % SLOWER inside the real pipeline: 8.9 vs 6.6 ms per step)
-        hipLaunchKernelGGL(attn_bf16_kernel_v3, grid, block, 0, (hipStream_t)stream, qkv, out, N, H);
-    else if (scale == 0.0f)  // Q pre-scaled by softmax_scale*log2(e): scores already in log2 units
-        hipLaunchKernelGGL(attn_bf16_kernel_v2, grid, block, 0, (hipStream_t)stream, qkv, out, N, H, g_attn_debug);
     else
         hipLaunchKernelGGL(attn_bf16_kernel, grid, block, 0, (hipStream_t)stream, qkv, out, N, H, scale * 1.44269504088896340736f);
     UFM_CHECK_LAUNCH("ufm_attention_bf16");

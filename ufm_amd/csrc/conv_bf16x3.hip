@@ -239,16 +239,13 @@ extern "C" int ufm_conv2d_nhwc_bf16x3(const uint16_t* in, int B, int H, int W, i
             hipLaunchKernelGGL((conv_x3_kernel<128, 32, 2>), dim3(ntm * (Cout / 32)), dim3(256), 0, (hipStream_t)stream, q);
         }
     };
-    // 8-phase tile: 256 px x 256 cout when Cout % 256 == 0, else 512 px x 128 cout when Cout % 128 == 0
-    const int tile_n = Cout % 256 == 0 ? 256 : 128, tile_m = Cout % 256 == 0 ? 256 : 512;
-    const bool ok8 = Cout % 128 == 0 && KH * KW * (Cin / 32) >= 2 && p.in_plane < (1ll << 31) && p.w_plane < (1ll << 31);
+    // 8-phase tile: 256 px x 256 cout (Cout % 256 == 0)
+    const int tile_n = 256, tile_m = 256;
+    const bool ok8 = Cout % 256 == 0 && KH * KW * (Cin / 32) >= 2 && p.in_plane < (1ll << 31) && p.w_plane < (1ll << 31);
     const long long t8 = ((M + tile_m - 1) / tile_m) * (Cout / tile_n);
     if (ok8 && g_conv_variant == 2) {
         ufm_launch_conv_x3_8ph(p, (hipStream_t)stream);
-    } else if (ok8 && tile_n == 256 && g_conv_variant == 0 && t8 >= 256) {  // (variants 1 and 3 never take this branch)
-        // auto mode uses the 256 x 256 layout only: the 512 px x 128 cout layout (Cout = 128, all 160 KiB of LDS) measured
-        // SLOWER than the 128-row kernels on the one layer it applies to (296^2 256->128: 1328 vs 1130 us); it stays
-        // reachable through variant 2 and is covered by the bit-identity test
+    } else if (ok8 && g_conv_variant == 0 && t8 >= 256) {  // (variants 1 and 3 never take this branch)
         const long long full = t8 / 256;                                // whole rounds of the 8-phase kernel
         const long long m_main = full * 256 / (Cout / tile_n) * tile_m;  // leading pixels whose tiles fit in them
         if (m_main >= M || full == 0) {

@@ -248,12 +248,10 @@ __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
 }  // namespace
 
 int ufm_launch_conv_x3_8ph(const ConvX3Args& p, hipStream_t stream) {
-    if (p.Cout % 256 == 0) {
-        const int ntm = (p.M - p.m_begin + 255) / 256;
-        hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4>), dim3(ntm * (p.Cout / 256)), dim3(512), 0, stream, p);
-    } else {  // Cout % 128 == 0: 512 px x 128 cout tiles
-        const int ntm = (p.M - p.m_begin + 511) / 512;
-        hipLaunchKernelGGL((conv_x3_8ph_kernel<4, 2>), dim3(ntm * (p.Cout / 128)), dim3(512), 0, stream, p);
-    }
+    // 256 px x 256 cout tiles (wave layout 2 x 4).  The kernel is templated on the wave layout; the 4 x 2 layout (512 px x
+    // 128 cout for Cout = 128) measured slower than the 128-row kernels (296^2 256->128: 1328 vs 1130 us) and is no longer
+    // instantiated.
+    const int ntm = (p.M - p.m_begin + 255) / 256;
+    hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4>), dim3(ntm * (p.Cout / 256)), dim3(512), 0, stream, p);
     return 0;
 }

@@ -88,7 +88,8 @@ def save_png(path, array) -> None:
 
     a = np.asarray(array)
     if a.dtype != np.uint8:
-        a = np.clip(a, 0, 255).astype(np.uint8)  # cv2.imwrite saturates the same way
+        # cv2.imwrite (cli.py:140-146) converts float images with saturate_cast: round to nearest, then clamp
+        a = np.clip(np.rint(a), 0, 255).astype(np.uint8)
     Image.fromarray(a).save(str(path))
 
 
