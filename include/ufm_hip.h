@@ -152,8 +152,10 @@ int ufm_attention_bf16(const uint16_t* qkv, uint16_t* out, int B, int N, int H, 
 
 /* Diagnostics for the default ufm_attention_bf16 kernel (scale == 0 form): the same kernel with s_memtime stamps
  * around the four MFMA/softmax slots of every key tile (cdna_hip_programming.md section 7, "In-kernel stamps").
- * diag: 8 x uint64 per workgroup = {sync + DMA issue, slot 0, slot 1, slot 2, slot 3, whole kernel (shader cycles),
- * s_memrealtime ticks (100 MHz) of the whole kernel, key tiles}.  waves = 2 or 4 per workgroup.  Never on the product path. */
+ * diag: 16 x uint64 per workgroup = {sync + DMA issue, slot 0, slot 1, slot 2, slot 3, whole kernel (shader cycles),
+ * s_memrealtime ticks (100 MHz) of the whole kernel, key tiles, units, and per unit seam: state init, prologue wait + K
+ * fragment reads, next-unit DMA/Q issue, drain, epilogue compute, store issue, 0}.  waves = 2 or 4 per workgroup.
+ * Never on the product path. */
 int ufm_debug_attention_stamps(const uint16_t* qkv, uint16_t* out, int B, int N, int H, int waves,
                                unsigned long long* diag, void* stream);
 

@@ -16,7 +16,7 @@ def attn_ref(qkv, B, N, H, scale):
 
 
 for variant in (0, 1):
-    for B, N, H in ((1, 64, 1), (1, 100, 1), (1, 128, 1), (1, 129, 1), (1, 200, 1), (1, 300, 1), (2, 100, 2), (1, 1370, 1)):
+    for B, N, H in ((1, 64, 1), (1, 100, 1), (1, 129, 1), (1, 300, 1), (2, 100, 2), (2, 1370, 16), (1, 2738, 12)):
         g = torch.Generator().manual_seed(N)
         qkv = (torch.randn(B * N, 3 * H * 64, generator=g) * 1.5).bfloat16().float()
         c = 0.125 * 1.4426950408889634

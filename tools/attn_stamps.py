@@ -18,24 +18,26 @@ def main():
         qkv = torch.randn(b * n, 3 * h * 64, device="cuda").bfloat16()
         qkv[:, : h * 64] = (qkv[:, : h * 64].float() * (0.125 * 1.4426950408889634)).bfloat16()
         out = torch.empty(b * n, h * 64, device="cuda", dtype=torch.bfloat16)
-        for waves in (4, 20, 2):
-            nqb = (n + (waves & 15) * 64 - 1) // ((waves & 15) * 64)
+        for waves in (4, 2):
+            nqb = (n + waves * 64 - 1) // (waves * 64)
             nwg = nqb * h * b
-            diag = torch.zeros(nwg * 8, device="cuda", dtype=torch.int64)
+            diag = torch.zeros(nwg * 16, device="cuda", dtype=torch.int64)
             st = torch.cuda.current_stream().cuda_stream
             for _ in range(20):  # let the clock settle under load
                 hip._check(lib.ufm_debug_attention_stamps(qkv.data_ptr(), out.data_ptr(), b, n, h, waves, diag.data_ptr(), st), "ufm_debug_attention_stamps")
             torch.cuda.synchronize()
-            d = diag.view(nwg, 8).double().cpu()
+            d = diag.view(nwg, 16).double().cpu()
+            d = d[d[:, 5] > 0]  # persistent kernel: min(units, CUs x workgroups per CU) workgroups write a row
             tiles = d[:, 7]
             med = lambda x: float(x.median())  # noqa: E731
             row = {
                 "per_tile_cycles": {k: med(d[:, i] / tiles) for i, k in enumerate(["sync_dma", "slot0", "slot1", "slot2", "slot3"])},
                 "loop_cycles_per_tile": med(d[:, :5].sum(1) / tiles),
                 "kernel_cycles_per_wg": med(d[:, 5]),
-                "outside_loop_cycles": med(d[:, 5] - d[:, :5].sum(1)),
+                "outside_loop_cycles_per_unit": med((d[:, 5] - d[:, :5].sum(1)) / d[:, 8]),
+                "per_unit_cycles": {k: med(d[:, 9 + i] / d[:, 8]) for i, k in enumerate(["state_init", "prologue_wait_kreads", "seam_issue", "drain", "epilogue_compute", "store_issue"])},
                 "clock_ghz": med(d[:, 5] / d[:, 6] * 0.1),
-                "workgroups": nwg,
+                "units": nwg, "workgroups": int(d.shape[0]),
             }
             res[f"{name}_w{waves}"] = row
             print(name, "waves", waves, json.dumps(row), flush=True)

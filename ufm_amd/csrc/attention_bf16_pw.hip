@@ -104,10 +104,8 @@ __device__ __forceinline__ void o_read_all(float (&ov)[2][2][16]) {
 }
 template <int R0, int N, int I = 0>
 __device__ __forceinline__ void o_zero_range() {
-    if constexpr (I < N) {
-        o_zero<R0 + I>();
-        o_zero_range<R0, N, I + 1>();
-    }
+    static_assert(R0 == 0 && N == 64, "one statement zeroes all of a[0:63]");
+    asm volatile("v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tv_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\tv_accvgpr_write_b32 a4, 0\n\tv_accvgpr_write_b32 a5, 0\n\tv_accvgpr_write_b32 a6, 0\n\tv_accvgpr_write_b32 a7, 0\n\tv_accvgpr_write_b32 a8, 0\n\tv_accvgpr_write_b32 a9, 0\n\tv_accvgpr_write_b32 a10, 0\n\tv_accvgpr_write_b32 a11, 0\n\tv_accvgpr_write_b32 a12, 0\n\tv_accvgpr_write_b32 a13, 0\n\tv_accvgpr_write_b32 a14, 0\n\tv_accvgpr_write_b32 a15, 0\n\tv_accvgpr_write_b32 a16, 0\n\tv_accvgpr_write_b32 a17, 0\n\tv_accvgpr_write_b32 a18, 0\n\tv_accvgpr_write_b32 a19, 0\n\tv_accvgpr_write_b32 a20, 0\n\tv_accvgpr_write_b32 a21, 0\n\tv_accvgpr_write_b32 a22, 0\n\tv_accvgpr_write_b32 a23, 0\n\tv_accvgpr_write_b32 a24, 0\n\tv_accvgpr_write_b32 a25, 0\n\tv_accvgpr_write_b32 a26, 0\n\tv_accvgpr_write_b32 a27, 0\n\tv_accvgpr_write_b32 a28, 0\n\tv_accvgpr_write_b32 a29, 0\n\tv_accvgpr_write_b32 a30, 0\n\tv_accvgpr_write_b32 a31, 0\n\tv_accvgpr_write_b32 a32, 0\n\tv_accvgpr_write_b32 a33, 0\n\tv_accvgpr_write_b32 a34, 0\n\tv_accvgpr_write_b32 a35, 0\n\tv_accvgpr_write_b32 a36, 0\n\tv_accvgpr_write_b32 a37, 0\n\tv_accvgpr_write_b32 a38, 0\n\tv_accvgpr_write_b32 a39, 0\n\tv_accvgpr_write_b32 a40, 0\n\tv_accvgpr_write_b32 a41, 0\n\tv_accvgpr_write_b32 a42, 0\n\tv_accvgpr_write_b32 a43, 0\n\tv_accvgpr_write_b32 a44, 0\n\tv_accvgpr_write_b32 a45, 0\n\tv_accvgpr_write_b32 a46, 0\n\tv_accvgpr_write_b32 a47, 0\n\tv_accvgpr_write_b32 a48, 0\n\tv_accvgpr_write_b32 a49, 0\n\tv_accvgpr_write_b32 a50, 0\n\tv_accvgpr_write_b32 a51, 0\n\tv_accvgpr_write_b32 a52, 0\n\tv_accvgpr_write_b32 a53, 0\n\tv_accvgpr_write_b32 a54, 0\n\tv_accvgpr_write_b32 a55, 0\n\tv_accvgpr_write_b32 a56, 0\n\tv_accvgpr_write_b32 a57, 0\n\tv_accvgpr_write_b32 a58, 0\n\tv_accvgpr_write_b32 a59, 0\n\tv_accvgpr_write_b32 a60, 0\n\tv_accvgpr_write_b32 a61, 0\n\tv_accvgpr_write_b32 a62, 0\n\tv_accvgpr_write_b32 a63, 0" ::: UFM_O_CLOBBERS);
 }
 template <int R0, int N, int I = 0>
 __device__ __forceinline__ void o_scale_range(float f) {
@@ -122,7 +120,9 @@ __device__ __forceinline__ void o_scale_range(float f) {
 // M0 = LDS byte address of the piece (wave uniform); the s_nop is the M0-write -> LDS-DMA wait state.  M0 is written in the
 // same statement that uses it; the kernel has no compiler-generated M0 use (checked by tools/check_attn_isa.py).
 __device__ __forceinline__ void glds16(const char* gbase, unsigned voff, unsigned lds_addr) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(gbase) : "memory");
+    // leading s_nop 4: gbase / lds_addr may have been reloaded from a spilled SGPR by v_readlane right in front of the
+    // statement (VALU write of an SGPR -> VMEM read of it needs 5 wait states; nothing inside an asm string is padded)
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(gbase) : "memory");
 }
 __device__ __forceinline__ unsigned lds_addr_of(const char* p) { return (unsigned)(uintptr_t)LDS_PTR(p); }
 __device__ __forceinline__ void pad16() { asm volatile("s_nop 15\n\ts_nop 3" ::: "memory"); }
@@ -136,10 +136,10 @@ __device__ __forceinline__ unsigned long long stamp() {  // cdna_hip_programming
     return t;
 }
 
-template <int NW, bool DIAG, bool KV = false>
+template <int NW, bool DIAG>
 __global__ __launch_bounds__(NW * 64, 1) void attn_pw_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int N, int H, int nqb,
-                                                             unsigned long long* __restrict__ diag) {
-    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0}, t_prev = 0, t_begin = 0, rt_begin = 0;
+                                                             int nunits, unsigned long long* __restrict__ diag) {
+    unsigned long long seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0, t_begin = 0, rt_begin = 0;  // 0-4 key-tile slots, 5-10 unit seams
     if (DIAG) {
         t_begin = stamp();
         rt_begin = __builtin_amdgcn_s_memrealtime();
@@ -155,25 +155,38 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_pw_kernel(const uint16_t* __r
     __shared__ __attribute__((aligned(16))) char smem[OOFF + NW * 64 * OSTRIDE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int qblk = lid % nqb, head = (lid / nqb) % H, b = lid / (nqb * H);
+    // Persistent: the workgroup walks units (image, head, 64*NW-row query block) u, u + gridDim.x, ...; the units of one
+    // (image, head) are consecutive logical ids and, through xcd_remap, concurrent on one XCD (shared K/V stream in its L2).
+    int unit = xcd_remap(blockIdx.x, gridDim.x);
     const int ld = 3 * H * 64;
     const unsigned ldb = 2u * ld;
-    const uint16_t* base = qkv + (size_t)b * N * ld + head * 64;
-    const char* kp = (const char*)(base + H * 64);
-    const char* vp = (const char*)(base + 2 * H * 64);
     const int ql = lane & 31, hh = lane >> 5;
-    const int q0 = qblk * QB + wave * 64;
     const int nt = (N + KB - 1) / KB;
+    const uint16_t* base;
+    const char *kp, *vp;
+    uint16_t* og;
+    int q0;
+    auto set_unit = [&](int u) __attribute__((always_inline)) {
+        const int qblk = u % nqb, head = (u / nqb) % H, b = u / (nqb * H);
+        base = qkv + (size_t)b * N * ld + head * 64;
+        kp = (const char*)(base + H * 64);
+        vp = (const char*)(base + 2 * H * 64);
+        q0 = qblk * QB + wave * 64;
+        og = out + ((size_t)b * N + q0) * (H * 64) + head * 64;
+    };
+    set_unit(unit);
 
     // ---- Q fragments (B operand of S^T = K.Q^T): lane = query column ----
     bf16x8 qf[2][4];
+    auto load_q = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const uint16_t* qr = base + (size_t)min(q0 + 32 * a + ql, N - 1) * ld + 8 * hh;
+        for (int a = 0; a < 2; ++a) {
+            const uint16_t* qr = base + (size_t)min(q0 + 32 * a + ql, N - 1) * ld + 8 * hh;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qf[a][s] = *(const bf16x8*)(qr + 16 * s);
-    }
+            for (int s = 0; s < 4; ++s) qf[a][s] = *(const bf16x8*)(qr + 16 * s);
+        }
+    };
+    load_q();
 
     // ---- LDS-DMA source offsets: piece = 8 rows x 128 B, lane -> (row lane>>3, LDS slot lane&7) ----
     const int prow = lane >> 3, pslot = lane & 7;
@@ -219,11 +232,6 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_pw_kernel(const uint16_t* __r
     float lrun[2] = {0.f, 0.f}, ls[2] = {0.f, 0.f}, ls2[2] = {0.f, 0.f};
     float ev[16];     // exponentials of the half being processed (software pipelined one MFMA gap deep)
     unsigned pk[8];   // its packed bf16 pairs
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) negm[a][r] = 0.f;
-    o_zero_range<0, 64>();
 
     // fragment g (0..7) of the K tile: kf[g >> 2][g & 3];  tr-read pair g (0..7) of the V tile: vf[dt][kt][s2], g = 4dt + 2kt + s2
     auto read_k1 = [&](const char* kb, auto g_) __attribute__((always_inline)) {
@@ -239,8 +247,8 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_pw_kernel(const uint16_t* __r
     // MFMA g (0..7) of S^T(a) = K.Q^T(a) - m_ref(a) / of O^T(a) += V^T.P^T(a)
     auto qk1 = [&](auto a_, auto g_) __attribute__((always_inline)) {
         constexpr int A = decltype(a_)::value, G = decltype(g_)::value, KT = G >> 2, S = G & 3;
-        if (S == 0) mfma_qk_first<KV>(st[A][KT], kf[KT][0], qf[A][0], negm[A]);
-        else mfma_qk<KV>(st[A][KT], kf[KT][S], qf[A][S]);
+        if (S == 0) mfma_qk_first<false>(st[A][KT], kf[KT][0], qf[A][0], negm[A]);
+        else mfma_qk<false>(st[A][KT], kf[KT][S], qf[A][S]);
     };
     auto pv1 = [&](auto a_, auto g_) __attribute__((always_inline)) {
         constexpr int A = decltype(a_)::value, G = decltype(g_)::value, DT = G >> 2, KT = (G >> 1) & 1, S2 = G & 1;
@@ -355,6 +363,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_pw_kernel(const uint16_t* __r
     };
 
     // one MFMA gap: MFMA g of `what` + one softmax step + LDS fragment reads, fenced so that the order below is the order issued
+    char* const ob = smem + OOFF + wave * 64 * OSTRIDE;  // this wave's O staging rows
     // one 1-KiB piece of tile tt's K (ISV = 0) or V (1) image; SAFE: tt is a full tile known to exist
     auto dma_piece = [&](auto isv_, auto i_, auto safe_, char* lbuf, int tt) __attribute__((always_inline)) {
         constexpr int ISV = decltype(isv_)::value, I = decltype(i_)::value;
@@ -383,12 +392,14 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_pw_kernel(const uint16_t* __r
         char* vb_nxt = smem + VOFF + (PAR ^ 1) * 8192;
         const bool ragged_last = !SAFE && (t + 1) * KB > N;
         if (DIAG) t_prev = stamp();
-        // own DMA pieces of the previous iteration have landed; every wave has read K(t+1)... of the buffers re-filled below
-        wait_vm<0>();
-        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-        gap();
-        __builtin_amdgcn_s_barrier();
-        gap();
+        if (!FIRST) {  // (the first key tile was synchronised by the unit prologue)
+            // own DMA pieces of the previous iteration have landed; every wave has read the fragments of the buffers re-filled below
+            wait_vm<0>();
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+            gap();
+            __builtin_amdgcn_s_barrier();
+            gap();
+        }
         UFM_STAMP(0)
 #define UFM_GAPS(BODY) BODY(0) BODY(1) BODY(2) BODY(3) BODY(4) BODY(5) BODY(6) BODY(7)
         // ---- slot 0: QK^T_A(t) | softmax_B(t-1) keys 32..63 | DMA K(t+2) ----
@@ -448,72 +459,118 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_pw_kernel(const uint16_t* __r
 #undef UFM_S3
     };
 
-    // ---- prologue ----
-    dma(kp, dma_kc, dma_ko, smem + KOFF, 0);
-    dma(vp, dma_vc, dma_vo, smem + VOFF, 0);
-    if (nt > 1) dma(kp, dma_kc, dma_ko, smem + KOFF + 8192, 1);
-    wait_vm<0>();
-    gap();
-    __builtin_amdgcn_s_barrier();
-    gap();
-    read_k1(smem + KOFF, IC<0>{}); read_k1(smem + KOFF, IC<1>{}); read_k1(smem + KOFF, IC<2>{}); read_k1(smem + KOFF, IC<3>{});
-    read_k1(smem + KOFF, IC<4>{}); read_k1(smem + KOFF, IC<5>{}); read_k1(smem + KOFF, IC<6>{}); read_k1(smem + KOFF, IC<7>{});
-
-    iter(0, IC<0>{}, IC<1>{}, IC<0>{});
-    {
-        int t = 1;
-        for (; t + 4 < nt; t += 2) {  // tiles t+2 / t+3 exist and are full: no conditions around the DMA
-            iter(t, IC<1>{}, IC<0>{}, IC<1>{});
-            iter(t + 1, IC<0>{}, IC<0>{}, IC<1>{});
+    auto first_tiles = [&]() __attribute__((always_inline)) {  // K(0), V(0), K(1) of the current unit into the rings
+        dma(kp, dma_kc, dma_ko, smem + KOFF, 0);
+        dma(vp, dma_vc, dma_vo, smem + VOFF, 0);
+        if (nt > 1) dma(kp, dma_kc, dma_ko, smem + KOFF + 8192, 1);
+    };
+    first_tiles();
+    int units_done = 0;
+    bool stores_in_flight = false;  // wave-uniform: the previous unit ended with exactly 8 (unconditional) store instructions
+    for (;;) {
+        if (DIAG) t_prev = stamp();
+        // ---- unit prologue: state, first tiles landed and visible, K(0) fragments ----
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            lrun[a] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm[a][r] = 0.f;
         }
-        for (; t < nt; t += 2) {
-            iter(t, IC<1>{}, IC<0>{}, IC<0>{});
-            if (t + 1 < nt) iter(t + 1, IC<0>{}, IC<0>{}, IC<0>{});
-        }
-    }
-    // ---- drain: second half of q-block B's last tile ----
-    sm_all(IC<1>{}, IC<1>{});
-    check(IC<1>{});
-#define UFM_DR(G) pv1(IC<1>{}, IC<G>{});
-    UFM_GAPS(UFM_DR)
-#undef UFM_DR
-#undef UFM_GAPS
-    pad16();
+        o_zero_range<0, 64>();
+        UFM_STAMP(5)
+        // The first tiles and Q of this unit were requested BEFORE the previous unit's 8 O-row stores (vmcnt is in issue
+        // order): waiting for all but the 8 youngest operations leaves those stores draining under this unit's first key
+        // tile instead of in front of it (a CU's store path takes ~100 cycles per wave-instruction).
+        if (stores_in_flight) wait_vm<8>();
+        else wait_vm<0>();
+        gap();
+        __builtin_amdgcn_s_barrier();
+        gap();
+        read_k1(smem + KOFF, IC<0>{}); read_k1(smem + KOFF, IC<1>{}); read_k1(smem + KOFF, IC<2>{}); read_k1(smem + KOFF, IC<3>{});
+        read_k1(smem + KOFF, IC<4>{}); read_k1(smem + KOFF, IC<5>{}); read_k1(smem + KOFF, IC<6>{}); read_k1(smem + KOFF, IC<7>{});
+        UFM_STAMP(6)
 
-    // ---- epilogue: O[q][d] = O^T[d][q] / l, staged through this wave's LDS rows, stored as 128-B rows ----
-    char* ob = smem + OOFF + wave * 64 * OSTRIDE;
-    float ov[2][2][16];
-    o_read_all(ov);
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lrun[a]), __float_as_uint(lrun[a]), false, false);
-        const float inv = 1.0f / (__uint_as_float(sw[0]) + __uint_as_float(sw[1]));
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                u32x2 w = {pack_bf16x2(ov[a][dt][4 * g] * inv, ov[a][dt][4 * g + 1] * inv),
-                           pack_bf16x2(ov[a][dt][4 * g + 2] * inv, ov[a][dt][4 * g + 3] * inv)};
-                *(u32x2*)(ob + (32 * a + ql) * OSTRIDE + 2 * (32 * dt + 8 * g + 4 * hh)) = w;
+        iter(0, IC<0>{}, IC<1>{}, IC<0>{});
+        {
+            int t = 1;
+            for (; t + 4 < nt; t += 2) {  // tiles t+2 / t+3 exist and are full: no conditions around the DMA
+                iter(t, IC<1>{}, IC<0>{}, IC<1>{});
+                iter(t + 1, IC<0>{}, IC<0>{}, IC<1>{});
             }
-    }
-    uint16_t* og = out + ((size_t)b * N + q0) * (H * 64) + head * 64;
+            for (; t < nt; t += 2) {
+                iter(t, IC<1>{}, IC<0>{}, IC<0>{});
+                if (t + 1 < nt) iter(t + 1, IC<0>{}, IC<0>{}, IC<0>{});
+            }
+        }
+        if (DIAG) t_prev = stamp();
+        // ---- seam: the NEXT unit's first tiles and Q are requested now and land under this unit's drain + epilogue ----
+        uint16_t* const og_cur = og;
+        const int q0_cur = q0;
+        const int next = unit + (int)gridDim.x;
+        const bool has_next = next < nunits;
+        ++units_done;
+        if (has_next) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's last K/V fragment reads are back ...
+            gap();
+            __builtin_amdgcn_s_barrier();        // ... and so are every other wave's: the rings are free
+            gap();
+            set_unit(next);
+            first_tiles();
+            load_q();  // q fragments are dead after the last QK^T MFMA; the drain below only reads V and P
+        }
+        UFM_STAMP(7)
+        // ---- drain: second half of q-block B's last tile ----
+        sm_all(IC<1>{}, IC<1>{});
+        check(IC<1>{});
+#define UFM_DR(G) pv1(IC<1>{}, IC<G>{});
+        UFM_GAPS(UFM_DR)
+#undef UFM_DR
+        pad16();
+
+        UFM_STAMP(8)
+        // ---- epilogue: O[q][d] = O^T[d][q] / l, staged through this wave's LDS rows, stored as 128-B rows ----
+        float ov[2][2][16];
+        o_read_all(ov);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = 8 * i + prow;
-        const u32x4 v = *(const u32x4*)(ob + row * OSTRIDE + 16 * pslot);
-        if (q0 + row < N) *(u32x4*)(og + (size_t)row * (H * 64) + 8 * pslot) = v;
+        for (int a = 0; a < 2; ++a) {
+            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lrun[a]), __float_as_uint(lrun[a]), false, false);
+            const float inv = 1.0f / (__uint_as_float(sw[0]) + __uint_as_float(sw[1]));
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2 w = {pack_bf16x2(ov[a][dt][4 * g] * inv, ov[a][dt][4 * g + 1] * inv),
+                               pack_bf16x2(ov[a][dt][4 * g + 2] * inv, ov[a][dt][4 * g + 3] * inv)};
+                    *(u32x2*)(ob + (32 * a + ql) * OSTRIDE + 2 * (32 * dt + 8 * g + 4 * hh)) = w;
+                }
+        }
+        UFM_STAMP(9)
+        // Exactly 8 store instructions per wave when all its 64 rows exist (the count the next unit's vmcnt(8) relies on)
+        stores_in_flight = q0_cur + 64 <= N;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 8 * i + prow;
+            const u32x4 v = *(const u32x4*)(ob + row * OSTRIDE + 16 * pslot);
+            if (stores_in_flight || q0_cur + row < N) *(u32x4*)(og_cur + (size_t)row * (H * 64) + 8 * pslot) = v;
+        }
+        UFM_STAMP(10)
+        if (!has_next) break;
+        unit = next;
     }
+#undef UFM_GAPS
     if (DIAG) {  // stamps leave through a buffer of their own, never through an output element
         const unsigned long long t_end = stamp();
         const unsigned long long rt_end = __builtin_amdgcn_s_memrealtime();
         if (tid == 0) {
-            unsigned long long* d = diag + (size_t)blockIdx.x * 8;
+            unsigned long long* d = diag + (size_t)blockIdx.x * 16;
 #pragma unroll
             for (int k = 0; k < 5; ++k) d[k] = seg[k];
             d[5] = t_end - t_begin;
             d[6] = rt_end - rt_begin;
-            d[7] = (unsigned long long)nt;
+            d[7] = (unsigned long long)nt * units_done;
+            d[8] = (unsigned long long)units_done;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) d[9 + k] = seg[5 + k];
         }
     }
 #undef UFM_STAMP
@@ -521,26 +578,34 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_pw_kernel(const uint16_t* __r
 
 }  // namespace
 
+static int attn_pw_grid(int nunits, int nw) {  // persistent: one workgroup of 4 waves (two of 2 waves) per compute unit
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0, n = 0;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    const int slots = ncu * (nw == 4 ? 1 : 2);
+    return nunits < slots ? nunits : slots;
+}
+
 int ufm_launch_attn_pw(const uint16_t* qkv, uint16_t* out, int B, int N, int H, int variant, hipStream_t stream) {
     const int nw = (variant & 1) ? 2 : 4;
-    const int qb = nw * 64, nqb = (N + qb - 1) / qb;
-    dim3 grid(nqb * H * B), block(nw * 64);
-    if (nw == 4) hipLaunchKernelGGL((attn_pw_kernel<4, false>), grid, block, 0, stream, qkv, out, N, H, nqb, nullptr);
-    else hipLaunchKernelGGL((attn_pw_kernel<2, false>), grid, block, 0, stream, qkv, out, N, H, nqb, nullptr);
+    const int qb = nw * 64, nqb = (N + qb - 1) / qb, nunits = nqb * H * B;
+    dim3 grid(attn_pw_grid(nunits, nw)), block(nw * 64);
+    if (nw == 4) hipLaunchKernelGGL((attn_pw_kernel<4, false>), grid, block, 0, stream, qkv, out, N, H, nqb, nunits, nullptr);
+    else hipLaunchKernelGGL((attn_pw_kernel<2, false>), grid, block, 0, stream, qkv, out, N, H, nqb, nunits, nullptr);
     return 0;
 }
 
 // Diagnostics (tools/attn_stamps.py): the same kernel with s_memtime stamps around the four slots of every key tile.
-// diag: 8 x uint64 per workgroup = {sync+DMA issue, slot 0, slot 1, slot 2, slot 3, whole kernel, s_memrealtime ticks (100 MHz), tiles}.
+// diag: 16 x uint64 per workgroup = {sync + DMA issue, slot 0..3, whole kernel, s_memrealtime ticks (100 MHz), tiles, units,
+//       state init, prologue wait + K reads, seam, drain, epilogue compute, store issue, 0}.
 extern "C" int ufm_debug_attention_stamps(const uint16_t* qkv, uint16_t* out, int B, int N, int H, int waves, unsigned long long* diag, void* stream) {
-    const bool kv = waves >= 16;  // experiment: K fragments in VGPRs
-    waves &= 15;
     UFM_REQUIRE(qkv && out && diag && (waves == 2 || waves == 4), "ufm_debug_attention_stamps: bad arguments");
-    const int qb = waves * 64, nqb = (N + qb - 1) / qb;
-    dim3 grid(nqb * H * B), block(waves * 64);
-    if (waves == 4 && kv) hipLaunchKernelGGL((attn_pw_kernel<4, true, true>), grid, block, 0, (hipStream_t)stream, qkv, out, N, H, nqb, diag);
-    else if (waves == 4) hipLaunchKernelGGL((attn_pw_kernel<4, true>), grid, block, 0, (hipStream_t)stream, qkv, out, N, H, nqb, diag);
-    else hipLaunchKernelGGL((attn_pw_kernel<2, true>), grid, block, 0, (hipStream_t)stream, qkv, out, N, H, nqb, diag);
+    const int qb = waves * 64, nqb = (N + qb - 1) / qb, nunits = nqb * H * B;
+    dim3 grid(attn_pw_grid(nunits, waves)), block(waves * 64);
+    if (waves == 4) hipLaunchKernelGGL((attn_pw_kernel<4, true>), grid, block, 0, (hipStream_t)stream, qkv, out, N, H, nqb, nunits, diag);
+    else hipLaunchKernelGGL((attn_pw_kernel<2, true>), grid, block, 0, (hipStream_t)stream, qkv, out, N, H, nqb, nunits, diag);
     UFM_CHECK_LAUNCH("ufm_debug_attention_stamps");
     return UFM_OK;
 }
