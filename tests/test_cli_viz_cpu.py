@@ -64,3 +64,36 @@ def test_warp_has_no_cpu_fallback():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         viz.warp_image_with_flow(np.zeros((4, 4, 3), np.uint8), None, np.zeros((4, 4, 3), np.uint8), np.zeros((4, 4, 2), np.float32))
+
+
+def test_example_inference_figure(tmp_path):
+    """example_inference.py:45-90: the 2 x 3 figure (host side; the warped panel is passed in because the warp is a GPU kernel)."""
+    from PIL import Image
+
+    from ufm_amd import example_inference as ex
+
+    rng = np.random.default_rng(1)
+    src = rng.integers(0, 256, (30, 40, 3), dtype=np.uint8)
+    tgt = rng.integers(0, 256, (30, 40, 3), dtype=np.uint8)
+    flow = rng.normal(size=(2, 30, 40)).astype(np.float32)
+    cov = rng.random((30, 40)).astype(np.float32)
+    out = tmp_path / "fig.png"
+    fig = ex.visualize_results(src, tgt, flow, cov, str(out), warped_image=np.clip(tgt / 255.0, 0, 1))
+    assert len(fig.axes) == 7  # 6 panels + the colour bar
+    titles = [a.get_title() for a in fig.axes[:6]]
+    assert titles == ["Source Image", "Target Image", "Warped Source Image", "Flow Visualization (Valid at Covisible Pixels)",
+                      "Covisibility Mask (>0.5)", "Covisibility Confidence"]
+    im = Image.open(out)
+    assert im.size[0] > 800 and im.size[1] > 500
+    with pytest.raises(ValueError, match="Could not load image"):
+        ex.load_image(tmp_path / "missing.png")
+
+
+def test_save_png_rounds_like_cv2(tmp_path):
+    """cv2.imwrite saturate-casts float images (round to nearest, clamp); ADVICE r1: truncation biased every level down."""
+    from PIL import Image
+
+    a = np.array([[[0.4, 0.5, 0.6], [254.5, 255.7, -3.0]]], dtype=np.float32)
+    viz.save_png(tmp_path / "x.png", a)
+    got = np.array(Image.open(tmp_path / "x.png"))
+    assert got.tolist() == [[[0, 0, 1], [254, 255, 0]]]  # rint: halves to even
