@@ -115,6 +115,9 @@ def main():
 
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:  # UFM_BENCH_FORCE_DIST=1 without a launcher: a one-rank group on the real backend
+            for k_, v_ in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_PORT", "29533")):
+                os.environ.setdefault(k_, v_)
         dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
     import ufm_amd

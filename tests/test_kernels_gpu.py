@@ -302,6 +302,44 @@ def test_attention_bf16_pw_repeatable_full_size(hip, variant):
             lib.ufm_debug_set_attn_variant(0)
 
 
+def test_attention_bf16_pw_repeatable_beside_another_stream(hip):
+    """The engine runs two micro-batches on two HIP streams, so every kernel shares the chip with the other stream's
+    kernels: workgroups start late, staggered and with a cold instruction cache.  The encoder-shaped attention launch must
+    stay bitwise repeatable while a second stream runs the qkv GEMM (the pairing that exposed a missing barrier between the
+    K(0) fragment reads and the K(2) LDS-DMA into the same ring buffer)."""
+    import threading
+
+    B, N, H, D = 8, 1370, 12, 768
+    qkv = rnd(B * N, 3 * H * 64, seed=5, scale=1.0).to(DEV).bfloat16()
+    ref = torch.zeros(B * N, H * 64, device=DEV, dtype=torch.bfloat16)
+    hip.attention(qkv, ref, B, N, H, 0.0)
+    torch.cuda.synchronize()
+    A = rnd(B * N, D, seed=6, scale=1.0).to(DEV).bfloat16()
+    Wt = rnd(3 * D, D, seed=7, scale=0.03).to(DEV).bfloat16()
+    gout = torch.empty(B * N, 3 * D, device=DEV, dtype=torch.bfloat16)
+    side = torch.cuda.Stream()
+    stop = []
+
+    def load():
+        with torch.cuda.stream(side):
+            while not stop:
+                for _ in range(10):
+                    hip.gemm_bf16(A, Wt, B * N, 3 * D, D, gout)
+                side.synchronize()
+
+    t = threading.Thread(target=load)
+    t.start()
+    try:
+        for rep in range(60):
+            got = torch.zeros_like(ref)
+            hip.attention(qkv, got, B, N, H, 0.0)
+            torch.cuda.synchronize()
+            assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), rep
+    finally:
+        stop.append(1)
+        t.join()
+
+
 def test_attention_bf16_spike_forces_rescale(hip):
     """A late key with a huge score forces the online-softmax rescale branch (rule 26)."""
     B, N, H = 1, 300, 1

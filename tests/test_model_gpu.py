@@ -369,6 +369,29 @@ def test_full_size_batch_shards_are_bitwise_equal_across_kernel_dispatch(env):
     assert torch.equal(again.flow.flow_output, wf) and torch.equal(again.covisibility.mask, wm)
 
 
+def test_two_stream_micro_batches_are_repeatable_at_benchmark_batch(env):
+    """bench.py's workload itself (UFM-Base, 8 pairs at 518^2 = two concurrent micro-batches of 4): two identical calls
+    agree bit for bit and pairs 0 / 4 / 7 equal their one-pair runs.  (A workgroup's first attention unit used to be
+    timing dependent under the other stream's load; the 5-pair test above is too small to show it.)"""
+    ufm_amd, _ = env
+    from ufm_amd.modules import init_weights_
+
+    model = ufm_amd.UniFlowMatchConfidence(**ufm_amd.ufm_base_config()).eval()
+    init_weights_(model, seed=0)
+    model = model.to(DEV).set_numerics("fast")
+    assert model.engine().micro_batches == 2
+    src, tgt = u8((8, 518, 518, 3), 21).to(DEV), u8((8, 518, 518, 3), 22).to(DEV)
+    whole = model.predict_correspondences_batched(src, tgt)
+    wf, wm = whole.flow.flow_output.clone(), whole.covisibility.mask.clone()
+    for rep in range(3):
+        again = model.predict_correspondences_batched(src, tgt)
+        assert torch.equal(again.flow.flow_output, wf) and torch.equal(again.covisibility.mask, wm), rep
+    for i in (0, 4, 7):
+        one = model.predict_correspondences_batched(src[i : i + 1], tgt[i : i + 1])
+        assert torch.equal(one.flow.flow_output[0], wf[i]), i
+        assert torch.equal(one.covisibility.mask[0], wm[i]), i
+
+
 def test_hip_graph_replay_is_bitwise_eager(env):
     """ufm_amd.GraphedPredictor: one predict_correspondences_batched captured into a HIP graph (the C ABI never allocates
     or synchronises); replays on new inputs must equal the eager call bit for bit -- tiny model incl. a non-identity

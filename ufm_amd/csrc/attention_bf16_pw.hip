@@ -488,6 +488,13 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_pw_kernel(const uint16_t* __r
         gap();
         read_k1(smem + KOFF, IC<0>{}); read_k1(smem + KOFF, IC<1>{}); read_k1(smem + KOFF, IC<2>{}); read_k1(smem + KOFF, IC<3>{});
         read_k1(smem + KOFF, IC<4>{}); read_k1(smem + KOFF, IC<5>{}); read_k1(smem + KOFF, IC<6>{}); read_k1(smem + KOFF, IC<7>{});
+        // Tile 0's slot 0 re-fills K buffer 0 with K(2): every wave's K(0) fragments must be in registers first.  (Without
+        // this second barrier a wave delayed between the barrier above and its reads -- a cold instruction cache on a
+        // workgroup's first unit, another stream's kernels on the chip -- read rows of K(2) as K(0).)
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+        gap();
+        __builtin_amdgcn_s_barrier();
+        gap();
         UFM_STAMP(6)
 
         iter(0, IC<0>{}, IC<1>{}, IC<0>{});
