@@ -26,7 +26,8 @@ FAM = {"gemm_bf16": "ufm_gemm_bf16", "attn_bf16_kernel": "ufm_attention_bf16", "
        "patchify": "ufm_patchify", "unmap": "ufm_unmap", "conv_f32": "ufm_conv2d_nhwc_f32"}
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in ("pmc_step_fetch", "pmc_step_write", "pmc_step_util"):
-    for f in glob.glob(f"gpurun_out/{d}/*/*counter_collection.csv"):
+    files = sorted(glob.glob(f"gpurun_out/{d}/*/*counter_collection.csv"), key=os.path.getmtime)
+    for f in files[-1:]:  # gpurun_out/ keeps earlier calls' files: only the newest pass counts
         for r in csv.DictReader(open(f)):
             fam = next((v for k, v in FAM.items() if k in r["Kernel_Name"]), None)
             if fam:
