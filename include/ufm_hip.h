@@ -96,9 +96,12 @@ int ufm_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M,
 /* Tuning hooks (tests / tools only; the product path never calls them).
  * variant: 0 = auto (cost model per shape), 1 = 128x128 kernel, 4 = 256x256 8-phase kernel, 5 = hybrid (8-phase on the rows
  * that fill whole rounds of the chip + 128x128 on the rest).  flags (timing diagnostics, results are wrong): 2 = no DMA,
- * 4 = no epilogue traffic, 8 = direct (un-staged) epilogue of the 128x128 kernel (results right). */
+ * 4 = no epilogue traffic, 8 = direct (un-staged) epilogue of the 128x128 kernel (results right), 16 / 32 = lda / ldw taken
+ * as 0 (cache-hit probe), bits 8..15 = grouped-rasterization height of the 8-phase kernel (results right).
+ * tile_rows: 0 = cost model, 160 / 192 / 224 / 256 = pin the row height of the 8-phase tiles (results are bitwise the same). */
 int ufm_debug_set_gemm_variant(int variant);
 int ufm_debug_set_gemm_flags(int flags);
+int ufm_debug_set_gemm_tile_rows(int rows);
 /* Tuning hook for ufm_attention_bf16 (scale == 0 form): 0 = 4 waves per workgroup (default), 1 = 2 waves per workgroup. */
 int ufm_debug_set_attn_variant(int v);
 /* Tuning hook for ufm_conv2d_nhwc_bf16x3: 0 = auto, 1 = 128-row kernels only, 2 = 256x256 8-phase kernel wherever applicable,

@@ -78,7 +78,7 @@ def test_gemm_bf16(hip, M, N, K, act, use_gamma, use_res, out_bf16, row_mod, row
     assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("M,N,K", [(256 * 9 + 77, 1024, 128), (256 * 7, 1024, 192), (5000, 2304, 768), (4 * 1370, 1024, 4096), (300, 256, 1024)])
+@pytest.mark.parametrize("M,N,K", [(256 * 9 + 77, 1024, 128), (256 * 7, 1024, 192), (5000, 2304, 768), (4 * 1370, 1024, 4096), (300, 256, 1024), (8 * 1369, 768, 768)])
 def test_gemm_8phase_bitwise_equals_128_kernel_repeated(hip, M, N, K):
     """Race screen for the counted-vmcnt schedule: the 8-phase kernel (variant 4) and the hybrid split (5) accumulate in
     the same K order as the 128x128 kernel (1), so all three must agree BIT FOR BIT -- over repeated launches (a DMA
@@ -93,17 +93,49 @@ def test_gemm_8phase_bitwise_equals_128_kernel_repeated(hip, M, N, K):
         hip.gemm_bf16(A, W, M, N, K, want, bias=bias, res=res)
         want_b = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
         hip.gemm_bf16(A, W, M, N, K, want_b, bias=bias, act=1)
-        for rep in range(6):
-            for variant in (4, 5):
+        # (variant, pinned tile rows): the 8-phase kernel at its four tile heights (160 / 192 / 224 rows skip the MFMA
+        # fragments past the tile's end; ragged last tiles at every height), the hybrid split and the cost model's own pick
+        for rep in range(3):
+            for variant, rows in ((4, 256), (4, 224), (4, 192), (4, 160), (5, 0), (0, 0)):
                 lib.ufm_debug_set_gemm_variant(variant)
+                lib.ufm_debug_set_gemm_tile_rows(rows)
                 got = torch.full((M, N), 3.0, device=DEV)
                 hip.gemm_bf16(A, W, M, N, K, got, bias=bias, res=res)
-                assert torch.equal(got, want), (variant, rep)
+                assert torch.equal(got, want), (variant, rows, rep)
                 got_b = torch.full((M, N), 3.0, device=DEV, dtype=torch.bfloat16)
                 hip.gemm_bf16(A, W, M, N, K, got_b, bias=bias, act=1)
-                assert torch.equal(got_b.view(torch.int16), want_b.view(torch.int16)), (variant, rep)
+                assert torch.equal(got_b.view(torch.int16), want_b.view(torch.int16)), (variant, rows, rep)
     finally:
         lib.ufm_debug_set_gemm_variant(0)
+        lib.ufm_debug_set_gemm_tile_rows(0)
+
+
+def test_gemm_8phase_tile_heights_with_row_tables(hip):
+    """The row-remapped epilogue (residual table indexed modulo a period, output rows skipping one slot per group -- the
+    patch-embed / view-embedding forms) under every 8-phase tile height: bitwise the 128x128 kernel's result."""
+    lib = hip.lib()
+    M, N, K, period = 4 * 2738, 768, 1024, 2738
+    A = bf16r(rnd(M, K, seed=1)).to(DEV).bfloat16()
+    W = bf16r(rnd(N, K, seed=2, scale=K**-0.5)).to(DEV).bfloat16()
+    bias, table = rnd(N, seed=3, scale=0.1).to(DEV), rnd(period, N, seed=5).to(DEV)
+    group = 1369
+    try:
+        want = {}
+        for variant, rows in ((1, 0), (4, 256), (4, 224), (4, 192), (4, 160), (0, 0)):
+            lib.ufm_debug_set_gemm_variant(variant)
+            lib.ufm_debug_set_gemm_tile_rows(rows)
+            a = torch.full((M, N), 3.0, device=DEV)
+            hip.gemm_bf16(A, W, M, N, K, a, bias=bias, res=table, res_row_mod=period)
+            b = torch.full((M + M // group, N), 3.0, device=DEV)
+            hip.gemm_bf16(A, W, M, N, K, b, bias=bias, out_row_group=group)
+            if variant == 1:
+                want = dict(a=a, b=b)
+                assert torch.all(b[0 :: group + 1] == 3.0)
+            else:
+                assert torch.equal(a, want["a"]) and torch.equal(b, want["b"]), (variant, rows)
+    finally:
+        lib.ufm_debug_set_gemm_variant(0)
+        lib.ufm_debug_set_gemm_tile_rows(0)
 
 
 @pytest.mark.parametrize("variant", [1, 4])

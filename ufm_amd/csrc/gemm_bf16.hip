@@ -111,8 +111,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     epilogue_lds<OUT_BF16>(p, acc, smem + wave * 16384, m0 + wr * 64, n0 + wc * 64, lane);
 }
 
-constexpr int PBM = 256;  // row tile of the 8-phase kernel (hybrid split arithmetic below)
-
 }  // namespace
 
 static int g_gemm_variant = 0;  // 0 auto, 1 = 128x128 kernel, 4 = 256x256 8-phase kernel, 5 = hybrid (8-phase on whole rounds + 128x128 on the rest)
@@ -125,8 +123,17 @@ extern "C" int ufm_debug_set_gemm_variant(int variant) {
     g_gemm_variant = variant;
     return UFM_OK;
 }
+static int g_gemm_tile_rows = 0;  // 0 = cost model; 160 / 192 / 224 / 256 pins the 8-phase tile height (tests, tools/lab)
+extern "C" int ufm_debug_set_gemm_tile_rows(int rows) {
+    if (rows != 0 && rows != 160 && rows != 192 && rows != 224 && rows != 256) {
+        ufm_set_error("ufm_debug_set_gemm_tile_rows: %d is not one of 0 (auto), 160, 192, 224, 256", rows);
+        return UFM_ERR_ARG;
+    }
+    g_gemm_tile_rows = rows;
+    return UFM_OK;
+}
 extern "C" int ufm_debug_set_gemm_flags(int flags) {
-    g_gemm_flags = flags & (2 | 4 | 8);
+    g_gemm_flags = flags & (2 | 4 | 8 | 16 | 32 | 0xff00);  // 16 / 32: lda / ldw = 0 (every tile reads the same rows: an all-L2-hit probe, tools/lab)
     return UFM_OK;
 }
 
@@ -144,6 +151,8 @@ extern "C" int ufm_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int 
     UFM_REQUIRE(out_dtype == UFM_F32 || out_dtype == UFM_BF16, "ufm_gemm_bf16: bad out_dtype %d", out_dtype);
     UFM_REQUIRE((size_t)M * (size_t)(lda > ldo ? lda : ldo) < (1ull << 40), "ufm_gemm_bf16: problem too large");
     GemmArgs p{A, W, bias, gamma, res, out, lda, ldw, M, N, K, act, ldres, res_row_mod, ldo, out_row_group, g_gemm_flags, 0};
+    if (g_gemm_flags & 16) p.lda = 0;
+    if (g_gemm_flags & 32) p.ldw = 0;
     static int ncu_cached = 0;  // compute units of the current device (whole rounds of the one-block-per-CU 8-phase kernel)
     if (ncu_cached == 0) {
         int dev = 0, n = 0;
@@ -151,39 +160,66 @@ extern "C" int ufm_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int 
         else ncu_cached = 256;
     }
     const int NCU = ncu_cached;
-    const int ntm256 = (M + PBM - 1) / PBM;
-    const int t256 = (N % 256 == 0) ? ntm256 * (N / 256) : 0;
-    // variant: 0 auto, 1 = 128x128, 4 = 256x256 8-phase, 5 = hybrid (8-phase on the leading rows that fill whole rounds
-    //          of the chip's CUs, 128x128 on the rest)
+    const int ntn = N / 256;
+    // variant: 0 auto, 1 = 128x128, 4 = 8-phase on all rows, 5 = hybrid (256-row 8-phase tiles on the leading rows that fill
+    //          whole rounds of the chip's CUs, the rest by whichever is cheaper: lower 8-phase tiles or the 128x128 kernel)
     int variant = g_gemm_variant;
     const bool fits32 = (long long)M * lda < (1ll << 31) && (long long)N * ldw < (1ll << 31);
-    const bool ok8 = t256 > 0 && K >= 128 && fits32;
-    int m_split = 0;  // rows [0, m_split) -> 8-phase kernel, [m_split, M) -> 128x128 kernel
+    const bool ok8 = N % 256 == 0 && K >= 128 && fits32;
+    // Cost model in units of one 256-row 8-phase tile (T4), fitted to tools/lab/gemm_tile_rows.py on the UFM shapes
+    // (profiles/r02/gemm_tile_rows.log): a full round of the 128x128 kernel (512 co-resident tiles of a quarter of the work)
+    // = 0.62 T4 (0.85 at K = 4096), a partly filled last round 0.8..1 of that, a second launch 0.3 T4.  An 8-phase tile of 32 nf rows costs
+    // C8_FIX + (1 - C8_FIX) nf / 8: the phase's L slot (LDS reads, DMA issue, two barriers) does not shrink with the MFMA
+    // count, the epilogue does -- so the fixed share depends on the epilogue (GELU + bf16 store: 0.55, fp32 read-modify-write:
+    // 0.7, plain bf16 store: 0.9).
+    const double C8_FIX = (act == UFM_ACT_GELU && out_dtype == UFM_BF16) ? 0.55 : (out_dtype == UFM_F32 ? 0.7 : 0.9);
+    auto rounds1 = [&](int rows) {
+        if (rows <= 0) return 0.0;
+        const long long t = (long long)((rows + 127) / 128) * (N / 128), per = 2 * NCU;
+        const long long full = t / per, rem = t % per;
+        const double w1 = 0.62 + 0.23 * (K <= 1024 ? 0.0 : K >= 4096 ? 1.0 : (K - 1024) / 3072.0);  // its main loop is the slower one: long K costs more
+        return w1 * ((double)full + (rem ? 0.8 + 0.2 * (double)rem / (double)per : 0.0));
+    };
+    auto cost8 = [&](int rows, int nf) {
+        const int h = 32 * nf;
+        const long long tiles = (long long)((rows + h - 1) / h) * ntn;
+        return 0.08 + 0.92 * (double)((tiles + NCU - 1) / NCU) * (C8_FIX + (1.0 - C8_FIX) * nf / 8.0);  // rounds after the first pipeline a little
+    };
+    auto best8 = [&](int rows, int& nf_out) {  // cheapest tile height for `rows` rows
+        double best = 1e30;
+        for (int nf = 8; nf >= 5; --nf) {
+            if (g_gemm_tile_rows && 32 * nf != g_gemm_tile_rows) continue;
+            const double c = cost8(rows, nf);
+            if (c < best - 1e-9) best = c, nf_out = nf;
+        }
+        return best;
+    };
+    int m_split = 0, nf_lead = 8, nf_rest = 0;  // rows [0, m_split): 8-phase at nf_lead; [m_split, M): 8-phase at nf_rest, or 128x128 if 0
     if (variant == 0 || variant == 5) {
-        // Cost model in units of one 8-phase tile (T4): a round of the 128x128 kernel (512 co-resident tiles of a
-        // quarter of the work) measured 0.62 T4, a second launch ~0.1 T4 (tools/gemm_ab.py, profiles/r01/gemm_ab_*.log).
-        // The 8-phase kernel only where it measured faster at all: wide N, K >= 512.
-        const int ntn = N / 256;
-        auto rounds1 = [&](int rows) { return rows <= 0 ? 0.0 : 0.62 * (double)(((long long)((rows + 127) / 128) * (N / 128) + 2 * NCU - 1) / (2 * NCU)); };
         double best = rounds1(M);
         int best_variant = 1;
-        if (ok8 && ((N >= 1024 && K >= 512) || (N >= 768 && K >= 2048) || variant == 5)) {
-            const double c4 = (double)((t256 + NCU - 1) / NCU);
-            if (c4 < best) best = c4, best_variant = 4;
-            const int full = t256 / NCU;                   // whole rounds of the 8-phase kernel
-            const int rows_main = full * NCU / ntn * 256;  // leading rows whose tiles fit in them
-            if (full > 0 && rows_main < M) {
-                const double c5 = full + rounds1(M - rows_main) + 0.1;
-                if (c5 < best || variant == 5) best = c5, best_variant = 5, m_split = rows_main;
+        // the 8-phase kernel only where it measured faster at all: wide N, K >= 512
+        if (ok8 && ((N >= 1024 && K >= 512) || (N >= 768 && K >= 768) || variant == 5)) {
+            int nf = 8;
+            const double c4 = best8(M, nf);
+            if (c4 < best) best = c4, best_variant = 4, nf_lead = nf;
+            const int full = (int)(((long long)((M + 255) / 256) * ntn) / NCU);  // whole rounds of 256-row tiles
+            const int rows_main = full * NCU / ntn * 256;                         // leading rows whose tiles fit in them
+            if (full > 0 && rows_main < M && !g_gemm_tile_rows) {
+                int nfr = 8;
+                const double r8 = best8(M - rows_main, nfr), r1 = rounds1(M - rows_main);
+                const double c5 = 0.08 + 0.92 * full + (r8 < r1 ? r8 : r1) + 0.3;
+                if (c5 < best || variant == 5) best = c5, best_variant = 5, m_split = rows_main, nf_lead = 8, nf_rest = r8 < r1 ? nfr : 0;
             }
         }
         variant = (variant == 5 && best_variant != 5) ? (ok8 ? 4 : 1) : best_variant;
+    } else if (variant == 4 && g_gemm_tile_rows) {
+        nf_lead = g_gemm_tile_rows / 32;
     }
     if ((variant == 4 || variant == 5) && !ok8) variant = 1;
-    if (!fits32) variant = 1;
     auto launch128 = [&](const GemmArgs& q) {
-        const int ntm = (q.M - q.m_begin + BM - 1) / BM, ntn = N / BN;
-        dim3 grid(ntm * ntn), block(256);
+        const int ntm = (q.M - q.m_begin + BM - 1) / BM, ntn128 = N / BN;
+        dim3 grid(ntm * ntn128), block(256);
         if (out_dtype == UFM_BF16)
             hipLaunchKernelGGL(gemm_bf16_kernel<1>, grid, block, 0, (hipStream_t)stream, q);
         else
@@ -193,10 +229,11 @@ extern "C" int ufm_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int 
         GemmArgs lead = p, rest = p;
         lead.M = m_split;
         rest.m_begin = m_split;
-        ufm_launch_gemm_8ph(lead, out_dtype, (hipStream_t)stream);
-        launch128(rest);
+        ufm_launch_gemm_8ph(lead, out_dtype, (hipStream_t)stream, 8);
+        if (nf_rest) ufm_launch_gemm_8ph(rest, out_dtype, (hipStream_t)stream, nf_rest);
+        else launch128(rest);
     } else if (variant == 4) {
-        ufm_launch_gemm_8ph(p, out_dtype, (hipStream_t)stream);
+        ufm_launch_gemm_8ph(p, out_dtype, (hipStream_t)stream, nf_lead);
     } else {
         launch128(p);
     }

@@ -31,20 +31,26 @@ constexpr int HALF = 128 * 64 * 2;  // 16 KiB half-tile
 template <int K>
 using IC = std::integral_constant<int, K>;
 
-template <int OUT_BF16>
+// NF = 16-row MFMA fragments per wave (5..8): the tile is 32 * NF rows high (wave group wr owns rows [wr * 16 NF, (wr + 1) * 16 NF)
+// of it; its second 64-row half simply has NF - 4 fragments).  Lower tiles make ceil(M / height) * (N / 256) fit whole rounds of
+// the chip where 256-row tiles would strand CUs (M = 10 952, N = 1024: 172 tiles on 256 CUs -> 232 tiles of 192 rows).  The
+// staging, the phase schedule and every output element's accumulation order are those of NF = 8.
+template <int OUT_BF16, int NF>
 __device__ __forceinline__ void gemm_bf16_8ph_body(const GemmArgs& p, char* smem) {
+    static_assert(NF >= 5 && NF <= 8, "NF");
+    constexpr int RW = 16 * NF, BMT = 2 * RW;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
 
     // ---- tile of this block: XCD chunking + grouped rasterization (as gemm_bf16.hip) ----
-    const int ntn = p.N >> 8, ntm = (p.M - p.m_begin + 255) >> 8;
+    const int ntn = p.N >> 8, ntm = (p.M - p.m_begin + BMT - 1) / BMT;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    constexpr int GM = 4;
+    const int GM = (p.debug >> 8) ? (p.debug >> 8) : 8;  // grouped rasterization height (tools/lab/gemm_gm_probe.py: flags >> 8); 8 vs 4: QKV -8 %, others +-1 %
     const int per_group = GM * ntn;
     const int grp = bid / per_group, in_g = bid - grp * per_group;
     const int gm = min(GM, ntm - grp * GM);
-    const int m0 = p.m_begin + ((grp * GM + in_g % gm) << 8), n0 = (in_g / gm) << 8;
+    const int m0 = p.m_begin + (grp * GM + in_g % gm) * BMT, n0 = (in_g / gm) << 8;
     const int nt = p.K >> 6;
 
     // ---- DMA source offsets (elements).  Wave w issues pieces w and 8+w of every half-tile; piece = 8 rows ----
@@ -56,7 +62,7 @@ __device__ __forceinline__ void gemm_bf16_8ph_body(const GemmArgs& p, char* smem
         const int chunk = (slot ^ srow) * 8;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int brow = (lr >> 6) * 128 + h * 64 + (lr & 63);  // X half h: rows mh = h of both wave groups
+            const int brow = (lr >> 6) * RW + h * 64 + (lr & 63);   // X half h: rows mh = h of both wave groups (rows past RW: unused)
             const int bcol = (lr >> 5) * 64 + h * 32 + (lr & 31);   // W half h: columns nh = h of the four wave columns
             xsrc[h][i] = 2u * ((unsigned)min(m0 + brow, p.M - 1) * (unsigned)p.lda + chunk);  // BYTE offsets: the DMA
             wsrc[h][i] = 2u * ((unsigned)(n0 + bcol) * (unsigned)p.ldw + chunk);               // address is sgpr base + vgpr32
@@ -93,6 +99,7 @@ __device__ __forceinline__ void gemm_bf16_8ph_body(const GemmArgs& p, char* smem
         const char* s = smem + ((tile & 1) * 4 + 1 + 2 * mh) * HALF + x_base;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            if (mh == 1 && i >= NF - 4) continue;
             xf[i][0] = *(const bf16x8*)(s + i * 2048 + ck0);
             xf[i][1] = *(const bf16x8*)(s + i * 2048 + ck1);
         }
@@ -115,7 +122,7 @@ __device__ __forceinline__ void gemm_bf16_8ph_body(const GemmArgs& p, char* smem
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < (MH == 0 ? 4 : NF - 4); ++i)
                     acc[MH][NH * 2 + j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][kk], xf[i][kk], acc[MH][NH * 2 + j][i], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -195,28 +202,33 @@ __device__ __forceinline__ void gemm_bf16_8ph_body(const GemmArgs& p, char* smem
         if (keep == 123.456f) ((float*)p.out)[0] = keep;
         return;
     }
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-        epilogue_lds<OUT_BF16>(p, acc[h], smem + wave * 16384, m0 + wr * 128 + h * 64, n0 + wc * 64, lane);
+    epilogue_lds<OUT_BF16, 64>(p, acc[0], smem + wave * 16384, m0 + wr * RW, n0 + wc * 64, lane);
+    epilogue_lds<OUT_BF16, RW - 64>(p, acc[1], smem + wave * 16384, m0 + wr * RW + 64, n0 + wc * 64, lane);
 }
 
-__global__ __launch_bounds__(512, 1) void gemm_bf16_8ph_kernel_bf16(GemmArgs p) {
+template <int OUT_BF16, int NF>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_8ph_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[8 * HALF];  // [tile & 1][kind]
-    gemm_bf16_8ph_body<1>(p, smem);
-}
-__global__ __launch_bounds__(512, 1) void gemm_bf16_8ph_kernel_f32(GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[8 * HALF];
-    gemm_bf16_8ph_body<0>(p, smem);
+    gemm_bf16_8ph_body<OUT_BF16, NF>(p, smem);
 }
 
 }  // namespace
 
-int ufm_launch_gemm_8ph(const GemmArgs& p, int out_dtype, hipStream_t stream) {
-    const int ntm = (p.M - p.m_begin + 255) / 256, ntn = p.N / 256;
+int ufm_launch_gemm_8ph(const GemmArgs& p, int out_dtype, hipStream_t stream, int nf) {
+    const int bmt = 32 * nf;
+    const int ntm = (p.M - p.m_begin + bmt - 1) / bmt, ntn = p.N / 256;
     dim3 grid(ntm * ntn), block(512);
-    if (out_dtype == UFM_BF16)
-        hipLaunchKernelGGL(gemm_bf16_8ph_kernel_bf16, grid, block, 0, stream, p);
-    else
-        hipLaunchKernelGGL(gemm_bf16_8ph_kernel_f32, grid, block, 0, stream, p);
+#define UFM_L8(NF_)                                                                                   \
+    case NF_:                                                                                         \
+        if (out_dtype == UFM_BF16)                                                                    \
+            hipLaunchKernelGGL((gemm_bf16_8ph_kernel<1, NF_>), grid, block, 0, stream, p);            \
+        else                                                                                          \
+            hipLaunchKernelGGL((gemm_bf16_8ph_kernel<0, NF_>), grid, block, 0, stream, p);            \
+        break;
+    switch (nf) {
+        UFM_L8(5) UFM_L8(6) UFM_L8(7) UFM_L8(8)
+        default: return 1;
+    }
+#undef UFM_L8
     return 0;
 }

@@ -71,9 +71,11 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[4][4], 
 // (conflict-free for both the accumulator-shaped writes and the row-shaped reads), then every wave
 // instruction moves 4 whole rows: 256-B fp32 / 128-B bf16 contiguous per row, for the residual read
 // (in-place update) and the store alike.  Within a wave LDS ops are in order: no barrier after the writes.
-template <int OUT_BF16>
+// ROWS (a multiple of 16, <= 64): only the first ROWS rows of the slice exist (8-phase tiles lower than 256 rows).
+template <int OUT_BF16, int ROWS = 64>
 __device__ __forceinline__ void epilogue_lds(const GemmArgs& p, f32x4 (&acc)[4][4], char* wave_lds, int row0, int col0,
                                              int lane) {
+    static_assert(ROWS % 16 == 0 && ROWS > 0 && ROWS <= 64, "ROWS");
     const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
@@ -82,7 +84,7 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& p, f32x4 (&acc)[4][
         if (p.bias) bv = *(const f32x4*)(p.bias + nb);
         if (p.gamma) gv = *(const f32x4*)(p.gamma + nb);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < ROWS / 16; ++m) {
             f32x4 v = acc[n][m] + bv;
             if (p.act == UFM_ACT_GELU && OUT_BF16) {
                 v = gelu_bf16_x4(v);
@@ -106,7 +108,7 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& p, f32x4 (&acc)[4][
             // a wave instruction covers 8 whole 128-B row segments
             const int r8 = lane >> 3, c8 = lane & 7;
 #pragma unroll
-            for (int pass = 0; pass < 8; ++pass) {
+            for (int pass = 0; pass < ROWS / 8; ++pass) {
                 const int r = pass * 8 + r8;
                 const f32x4 v0 = *(const f32x4*)(wave_lds + r * 256 + (((2 * c8) ^ (r & 15)) << 4));
                 const f32x4 v1 = *(const f32x4*)(wave_lds + r * 256 + (((2 * c8 + 1) ^ (r & 15)) << 4));
@@ -124,7 +126,7 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& p, f32x4 (&acc)[4][
         const int rr = lane >> 4, c = lane & 15;
         const int nb = col0 + c * 4;
 #pragma unroll
-        for (int pass = 0; pass < 16; ++pass) {
+        for (int pass = 0; pass < ROWS / 4; ++pass) {
             const int r = pass * 4 + rr;
             f32x4 v = *(const f32x4*)(wave_lds + r * 256 + ((c ^ (r & 15)) << 4));
             const int row = row0 + r;
@@ -143,7 +145,7 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& p, f32x4 (&acc)[4][
             }
         }
     };
-    if (row0 + 64 <= p.M && p.res_row_mod == 0 && p.out_row_group == 0)
+    if (row0 + ROWS <= p.M && p.res_row_mod == 0 && p.out_row_group == 0)
         readout(std::integral_constant<bool, true>{});
     else
         readout(std::integral_constant<bool, false>{});
@@ -159,4 +161,5 @@ __device__ __forceinline__ void wait_vmcnt() {
 }  // namespace
 
 // gemm_bf16_8ph.hip: 256x256 8-phase kernel (N % 256 == 0, K >= 128, 32-bit operand offsets)
-int ufm_launch_gemm_8ph(const GemmArgs& p, int out_dtype, hipStream_t stream);
+// nf = 16-row fragments per wave (5..8): tile height 32 * nf rows
+int ufm_launch_gemm_8ph(const GemmArgs& p, int out_dtype, hipStream_t stream, int nf = 8);

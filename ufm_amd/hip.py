@@ -32,6 +32,7 @@ SIGNATURES = {
     "ufm_gemm_bf16": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp],
     "ufm_debug_set_gemm_variant": [_i],
     "ufm_debug_set_gemm_flags": [_i],
+    "ufm_debug_set_gemm_tile_rows": [_i],
     "ufm_debug_set_attn_variant": [_i],
     "ufm_debug_set_conv_variant": [_i],
     "ufm_debug_set_upsample_variant": [_i],
