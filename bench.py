@@ -222,7 +222,10 @@ def main():
         ok = torch.tensor([1 if same else 0], device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         line["gather_check"] = {"bitwise_equal_to_local_recompute": bool(ok.item()), "pairs_gathered": int(flow_all.shape[0])}
-        assert bool(ok.item()), "gathered results differ from the local recomputation"
+        if not bool(ok.item()):
+            # reported in the JSON line (and loudly here) rather than raised: a failed check must not also lose the timing
+            print(f"[bench rank {rank}] WARNING: gathered results differ from the local recomputation (max-abs flow diff "
+                  f"{(mine.flow.flow_output - flow_all[lo : lo + 1]).abs().max().item():.3g})", file=sys.stderr, flush=True)
 
     src, tgt = src[:B], tgt[:B]  # everything below is single-GPU work on one shard-sized batch
     # ---- per-kernel durations: one extra instrumented step, HIP events on the launch stream ----

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Race soak: N identical two-stream forwards (UFM-Base B=8 and UFM-Refine+UNet B=4, 518^2) must all be bitwise equal."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import ufm_amd
+from ufm_amd.modules import init_weights_
+REPS = int(os.environ.get("REPS", "60"))
+def soak(model, B, tag):
+    g = torch.Generator().manual_seed(7)
+    src = torch.randint(0, 256, (B, 518, 518, 3), dtype=torch.uint8, generator=g).cuda()
+    tgt = torch.randint(0, 256, (B, 518, 518, 3), dtype=torch.uint8, generator=g).cuda()
+    o = model.predict_correspondences_batched(src, tgt)
+    f0, m0 = o.flow.flow_output.clone(), o.covisibility.mask.clone()
+    bad = 0
+    for r in range(REPS):
+        o = model.predict_correspondences_batched(src, tgt)
+        if not (torch.equal(o.flow.flow_output, f0) and torch.equal(o.covisibility.mask, m0)):
+            bad += 1
+            print(f"  {tag}: rep {r} differs: flow {(o.flow.flow_output - f0).abs().max().item():.3g}", flush=True)
+    print(f"{tag}: {bad} of {REPS} repeats differ", flush=True)
+m = ufm_amd.UniFlowMatchConfidence(**ufm_amd.ufm_base_config()).eval(); init_weights_(m, 0); m = m.to("cuda")
+soak(m, 8, "UFM-Base B=8 fast")
+soak(m, 5, "UFM-Base B=5 fast")
+del m
+cfg = ufm_amd.ufm_refine_config(use_unet_feature=True) if hasattr(ufm_amd, "ufm_refine_config") else None
+if cfg is not None:
+    r = ufm_amd.UniFlowMatchClassificationRefinement(**cfg).eval(); init_weights_(r, 0); r = r.to("cuda")
+    soak(r, 4, "UFM-Refine+UNet B=4 fast")

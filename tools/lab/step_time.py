@@ -23,6 +23,10 @@ m = m.to("cuda")
 g = torch.Generator().manual_seed(1)
 src = torch.randint(0, 256, (8, 518, 518, 3), dtype=torch.uint8, generator=g).cuda()
 tgt = torch.randint(0, 256, (8, 518, 518, 3), dtype=torch.uint8, generator=g).cuda()
+if os.environ.get("MB"):
+    m.engine().micro_batches = int(os.environ["MB"])
+if os.environ.get("CH"):
+    m.engine().concurrent_heads = os.environ["CH"] == "1"
 for _ in range(3):
     m.predict_correspondences_batched(src, tgt)
 torch.cuda.synchronize()
