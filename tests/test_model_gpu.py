@@ -257,6 +257,29 @@ def test_config5_1036_long_sequence_properties(env):
     assert d <= 0.025 * rng and dm <= 0.02  # measured 0.040 px on a range of 3.5 (1.1 %), mask 7e-3; bound = 2x measured
 
 
+def test_config5_1036_parity_vs_oracle(env):
+    """BASELINE config 5 against the oracle itself, one pair: the fp32 CPU oracle at 1036x1036 (5477-token encoder with the
+    37 -> 74 bicubic pos-embed interpolation, 10 954 joint tokens) vs numerics "parity" <= 1e-3 px -- the long-sequence
+    attention / LDS K-V ring path and the pos-embed rule pinned by more than self-consistency (a couple of CPU minutes)."""
+    ufm_amd, R = env
+    oracle = R.UFMRef(**R.ufm_base_config(resolution_wh=(1036, 1036))).eval()
+    R.init_weights_(oracle, 0)
+    prod = ufm_amd.UniFlowMatchConfidence(**ufm_amd.ufm_base_config(resolution_wh=(1036, 1036))).eval()
+    prod.load_state_dict(oracle.state_dict(), strict=True)
+    prod = prod.to(DEV)
+    src, tgt = u8((1, 1036, 1036, 3), 15), u8((1, 1036, 1036, 3), 16)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    o = oracle.predict_correspondences_batched(src, tgt)
+    p = prod.set_numerics("parity").predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
+    df, dm, mx = compare(o, p)
+    print(f"UFM-Base 1036 parity mode: flow max-abs {df:.3g} px (range {mx:.3g}), mask {dm:.3g}")
+    assert df <= 1e-3 and dm <= 1e-3, (df, dm, mx)
+    pf = prod.set_numerics("fast").predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
+    df2, dm2, _ = compare(o, pf)
+    print(f"UFM-Base 1036 fast mode: flow max-abs {df2:.3g} px (range {mx:.3g}), mask {dm2:.3g}")
+    assert df2 <= 0.03 * mx and dm2 <= 0.02, (df2, dm2, mx)
+
+
 def test_config1_shapes_unequal_sizes_multi_resolution(env):
     """BASELINE config 1 plumbing shapes (examples/image_pairs: 1080x1080, 1080x607 RGB, source and target of
     different size) on synthetic content, multi-resolution selection, tiny weights; vs the oracle in parity mode."""
