@@ -175,7 +175,6 @@ def test_ufm_base_full_size_parity(env):
     prod.load_state_dict(oracle.state_dict(), strict=True)
     prod = prod.to(DEV)
     src, tgt = u8((1, 518, 518, 3), 1234), u8((1, 518, 518, 3), 4321)
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
     o = oracle.predict_correspondences_batched(src, tgt)
     p = prod.set_numerics("parity").predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
     df, dm, mx = compare(o, p)
@@ -215,7 +214,6 @@ def test_config4_ufm_refine_full_size_parity(env):
     prod.load_state_dict(oracle.state_dict(), strict=True)
     prod = prod.to(DEV)
     src, tgt = u8((1, 518, 518, 3), 77), u8((1, 518, 518, 3), 78)
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
     o = oracle.predict_correspondences_batched(src, tgt)
     p = prod.set_numerics("parity").predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
     df, dm, mx = compare(o, p)
@@ -234,9 +232,9 @@ def test_config4_ufm_refine_full_size_parity(env):
 
 def test_config5_1036_long_sequence_properties(env):
     """BASELINE config 5: UFM-Base at 1036x1036 (5477 tokens/image, 10952 joint tokens; pos-embed bicubically
-    interpolated 37->74).  The fp32 CPU oracle would need minutes here, so the check is property-based: the bf16
-    and the exact-fp32 HIP paths (different kernels for every contraction) agree, results are finite,
-    deterministic, and independent of batch composition."""
+    interpolated 37->74), batch 2, size-independent properties: the bf16 and the exact-fp32 HIP paths (different
+    kernels for every contraction) agree, results are finite, deterministic, and independent of batch composition
+    (the comparison with the oracle at this size is test_config5_1036_parity_vs_oracle)."""
     ufm_amd, R = env
     prod = ufm_amd.UniFlowMatchConfidence(**ufm_amd.ufm_base_config(resolution_wh=(1036, 1036))).eval()
     ufm_amd.modules.init_weights_(prod, 0)
@@ -260,7 +258,7 @@ def test_config5_1036_long_sequence_properties(env):
 def test_config5_1036_parity_vs_oracle(env):
     """BASELINE config 5 against the oracle itself, one pair: the fp32 CPU oracle at 1036x1036 (5477-token encoder with the
     37 -> 74 bicubic pos-embed interpolation, 10 954 joint tokens) vs numerics "parity" <= 1e-3 px -- the long-sequence
-    attention / LDS K-V ring path and the pos-embed rule pinned by more than self-consistency (a couple of CPU minutes)."""
+    attention / LDS K-V ring path and the pos-embed rule pinned by more than self-consistency (~25 s on a 16-core share)."""
     ufm_amd, R = env
     oracle = R.UFMRef(**R.ufm_base_config(resolution_wh=(1036, 1036))).eval()
     R.init_weights_(oracle, 0)
@@ -268,7 +266,6 @@ def test_config5_1036_parity_vs_oracle(env):
     prod.load_state_dict(oracle.state_dict(), strict=True)
     prod = prod.to(DEV)
     src, tgt = u8((1, 1036, 1036, 3), 15), u8((1, 1036, 1036, 3), 16)
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
     o = oracle.predict_correspondences_batched(src, tgt)
     p = prod.set_numerics("parity").predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
     df, dm, mx = compare(o, p)
@@ -524,7 +521,7 @@ def test_unet_forward_against_reference_golden(env, golden_dir, numerics):
     prod = ufm_amd.UniFlowMatchClassificationRefinement(**ufm_amd.ufm_tiny_config(refine=True, use_unet_feature=True)).eval()
     ufm_amd.modules.init_weights_(prod, 0)
     ufm_amd.modules.init_weights_(prod.unet_feature, int(g["seed"]))  # the generator called init_weights_(reference UNet, seed)
-    wsum = float(sum(p.double().abs().sum() for p in prod.unet_feature.parameters()))
+    wsum = float(sum(p.detach().double().abs().sum() for p in prod.unet_feature.parameters()))
     assert abs(wsum - float(g["weight_abs_sum"])) <= 1e-6 * wsum
     prod = prod.to(DEV).set_numerics(numerics)
     eng = prod.engine()
@@ -585,7 +582,6 @@ def test_config4_variant_refine_with_unet_full_size(env):
     prod.load_state_dict(oracle.state_dict(), strict=True)
     prod = prod.to(DEV)
     src, tgt = u8((1, 518, 518, 3), 77), u8((1, 518, 518, 3), 78)
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
     o = oracle.predict_correspondences_batched(src, tgt)
     p = prod.set_numerics("parity").predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
     df, dm, mx = compare(o, p)
