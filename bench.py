@@ -96,7 +96,7 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the single-pair latency measurement")
     ap.add_argument("--gemm-variant", type=int, default=0, help="tuning hook: ufm_debug_set_gemm_variant (0 = auto)")
     ap.add_argument("--attn-variant", type=int, default=0, help="tuning hook: ufm_debug_set_attn_variant (0 = default)")
-    ap.add_argument("--concurrent-heads", action="store_true", help="run the two DPT heads on separate streams (measured: no gain)")
+    ap.add_argument("--concurrent-heads", type=int, default=-1, help="DPT heads on separate streams: -1 = engine default (automatic: only in single-stream forwards), 0 / 1 = force")
     ap.add_argument("--micro-batches", type=int, default=2, help="concurrent micro-batches (HIP streams) per GPU; 1 = single stream")
     args = ap.parse_args()
 
@@ -132,7 +132,8 @@ def main():
     init_weights_(model, seed=0)  # deterministic CPU RNG: identical weights on every rank
     model = model.to(dev).set_numerics(args.numerics)
     model.engine().micro_batches = args.micro_batches
-    model.engine().concurrent_heads = args.concurrent_heads
+    if args.concurrent_heads >= 0:
+        model.engine().concurrent_heads = bool(args.concurrent_heads)
 
     B = args.batch
     # Global batch = world x B pairs, generated identically on every rank (one seeded CPU stream); each rank computes

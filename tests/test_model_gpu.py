@@ -412,6 +412,30 @@ def test_two_stream_micro_batches_are_repeatable_at_benchmark_batch(env):
         assert torch.equal(one.covisibility.mask[0], wm[i]), i
 
 
+def test_concurrent_heads_are_bitwise_the_serial_heads(env):
+    """A single-stream forward runs the flow and the covisibility DPT head on two HIP streams (engine default for batches
+    that are not split into micro-batches); the heads share only their read-only input pyramid, so the result must be
+    bit for bit the serial one -- UFM-Base 518^2, one pair and three pairs, repeated."""
+    ufm_amd, _ = env
+    from ufm_amd.modules import init_weights_
+
+    model = ufm_amd.UniFlowMatchConfidence(**ufm_amd.ufm_base_config()).eval()
+    init_weights_(model, seed=0)
+    model = model.to(DEV).set_numerics("fast")
+    eng = model.engine()
+    assert eng.concurrent_heads is None  # automatic
+    for B in (1, 3):
+        src, tgt = u8((B, 518, 518, 3), 31).to(DEV), u8((B, 518, 518, 3), 32).to(DEV)
+        eng.concurrent_heads = False
+        ref = model.predict_correspondences_batched(src, tgt)
+        rf, rm = ref.flow.flow_output.clone(), ref.covisibility.mask.clone()
+        for mode in (True, None, True):
+            eng.concurrent_heads = mode
+            out = model.predict_correspondences_batched(src, tgt)
+            assert torch.equal(out.flow.flow_output, rf) and torch.equal(out.covisibility.mask, rm), (B, mode)
+    eng.concurrent_heads = None
+
+
 def test_hip_graph_replay_is_bitwise_eager(env):
     """ufm_amd.GraphedPredictor: one predict_correspondences_batched captured into a HIP graph (the C ABI never allocates
     or synchronises); replays on new inputs must equal the eager call bit for bit -- tiny model incl. a non-identity

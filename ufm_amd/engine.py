@@ -149,7 +149,10 @@ class Engine:
         self.micro_batches = 2  # >1: the batch is split into micro-batches that run concurrently on separate HIP streams
         self._streams: List[torch.cuda.Stream] = []
         self.fused_tail = True  # ufm_dpt_tail_fused where the head has the UFM-Base tail shape (bit-identical to the unfused path)
-        self.concurrent_heads = False  # measured: no gain on top of the two concurrent micro-batches (166 vs 168 pairs/s)
+        # DPT heads on separate HIP streams: None = automatic (yes for a single-stream forward -- one pair: 9.84 -> 8.97 ms
+        # graph replay, the small-grid layers of one head fill the other's tails -- no inside a micro-batch worker, where the
+        # other micro-batch already does that: 166 vs 168 pairs/s); True / False force it
+        self.concurrent_heads: Optional[bool] = None
         self._head_streams: Dict[str, List[torch.cuda.Stream]] = {}
 
     # ------------------------------------------------------------------ packing
@@ -640,7 +643,8 @@ class Engine:
         dims = [D, Di, Di, Di]
 
         out: Dict[str, Any] = {}
-        if len(self.heads) > 1 and self.concurrent_heads and hip.TIMER is None:
+        conc = self.concurrent_heads if self.concurrent_heads is not None else getattr(self._tls, "ns", "") == ""
+        if len(self.heads) > 1 and conc and hip.TIMER is None:
             # the heads only share their (read-only) input pyramid: run them on separate HIP streams so the
             # latency-bound small-grid layers of one overlap the large layers of the other
             main = torch.cuda.current_stream(self.dev)
