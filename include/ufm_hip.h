@@ -286,10 +286,10 @@ int ufm_resize_nearest_nhwc(const void* in, int dtype, int B, int H, int W, int 
 int ufm_unet_combine(const float* cls, const void* unet, int unet_dtype, int N, int HW, int ldu, const float* w1,
                      const float* b1, const float* w2, const float* b2, int method, float* out, void* stream);
 
-/* Pixel shuffle for MLPFeature ([U], call site models/ufm.py:965): x fp32 [B*g*g][C*p*p]
- * (column = (c, i, j)) -> planar [B][C][g*p][g*p]. */
-int ufm_pixel_shuffle_planar(const float* x, int B, int gh, int gw, int C, int p, float* out,
-                             void* stream);
+/* Pixel shuffle for MLPFeature ([U], call site models/ufm.py:965): x [B*g*g][C*p*p] (column = (c, i, j)), fp32 or the
+ * UFM_BF16X2 pair of planes (value = hi + lo) -> fp32 planar [B][C][g*p][g*p]. */
+int ufm_pixel_shuffle_planar(const void* x, int in_dtype /* UFM_F32 | UFM_BF16X2 */, int B, int gh, int gw, int C, int p,
+                             float* out, void* stream);
 
 /* Elementwise helpers used by the host wiring. */
 int ufm_cast_f32_to_bf16(const float* in, uint16_t* out, int64_t n, void* stream);

@@ -552,6 +552,13 @@ def test_pixel_shuffle_and_misc(hip):
     out = torch.zeros(B, Cc, gh * p, gw * p, device=DEV)
     hip.pixel_shuffle_planar(x.to(DEV), B, gh, gw, Cc, p, out)
     assert torch.equal(out.cpu(), ref)
+    # split-format input (the bf16x3 classification head's output): value = hi + lo
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    out2 = torch.zeros_like(out)
+    hip.pixel_shuffle_planar(torch.stack([hi, lo]).contiguous().to(DEV), B, gh, gw, Cc, p, out2, split=True)
+    ref2 = F.pixel_shuffle((hi.float() + lo.float()).reshape(B, gh, gw, Cc * p * p).permute(0, 3, 1, 2), p)
+    assert torch.equal(out2.cpu(), ref2)
     a, b = rnd(1024, seed=2), rnd(1024, seed=3)
     o = torch.zeros(1024, device=DEV)
     hip.add_f32(a.to(DEV), b.to(DEV), o)

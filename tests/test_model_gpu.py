@@ -219,6 +219,17 @@ def test_config4_ufm_refine_full_size_parity(env):
     df, dm, mx = compare(o, p)
     print(f"UFM-Refine 518 parity mode: flow max-abs {df:.3g} px (range {mx:.3g}), mask {dm:.3g}")
     assert df <= 1e-3 and dm <= 1e-3, (df, dm, mx)
+    # fp32 trunk + bf16x3 everywhere "fast" uses it in the fp32 island: DPT heads AND the classification MLP (two 1x1
+    # split-precision convolutions fed by split-format LayerNorm outputs) -- still inside the 1e-3 px gate
+    px = prod.set_numerics("parity_x3heads").predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
+    dfx, dmx, _ = compare(o, px)
+    print(f"UFM-Refine 518 fp32 trunk + bf16x3 heads and classification MLP: flow max-abs {dfx:.3g} px, mask {dmx:.3g}")
+    assert dfx <= 1e-3 and dmx <= 1e-3, (dfx, dmx, mx)
+    pf = prod.set_numerics("fast").predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
+    dff, dmf, _ = compare(o, pf)
+    print(f"UFM-Refine 518 fast mode: flow max-abs {dff:.3g} px (range {mx:.3g}), mask {dmf:.3g}")
+    assert dff <= 0.03 * mx and dmf <= 0.02, (dff, dmf, mx)
+    prod.set_numerics("parity")
     # lower-level forward exposes the refinement bundle (ufm.py:1001-1007)
     a = torch.randn(1, 3, 518, 518, generator=torch.Generator().manual_seed(5))
     v = lambda t: {"img": t.to(DEV), "symmetrized": False, "data_norm_type": "dinov2"}  # noqa: E731

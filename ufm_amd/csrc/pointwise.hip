@@ -371,16 +371,24 @@ __global__ __launch_bounds__(256) void unmap_channels_kernel(const float* __rest
     }
 }
 
-// x [B*gh*gw][C*p*p] (col = (c,i,j)) -> out planar [B][C][gh*p][gw*p]
-__global__ __launch_bounds__(256) void pixel_shuffle_kernel(const float* __restrict__ x, int B, int gh, int gw, int C,
+// x [B*gh*gw][C*p*p] (col = (c,i,j)) -> out planar [B][C][gh*p][gw*p].  SPLIT: x is the UFM_BF16X2 pair of planes (value = hi + lo)
+template <int SPLIT>
+__global__ __launch_bounds__(256) void pixel_shuffle_kernel(const void* __restrict__ xv, int B, int gh, int gw, int C,
                                                             int p, float* __restrict__ out) {
     const int Ho = gh * p, Wo = gw * p;
     const size_t total = (size_t)B * C * Ho * Wo;
+    const size_t plane = (size_t)B * gh * gw * C * p * p;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
         const int ox = (int)(t % Wo), oy = (int)((t / Wo) % Ho);
         const int c = (int)((t / ((size_t)Wo * Ho)) % C), b = (int)(t / ((size_t)Wo * Ho * C));
         const int gy = oy / p, i = oy - gy * p, gx = ox / p, j = ox - gx * p;
-        out[t] = x[(((size_t)b * gh + gy) * gw + gx) * ((size_t)C * p * p) + (c * p + i) * p + j];
+        const size_t src = (((size_t)b * gh + gy) * gw + gx) * ((size_t)C * p * p) + (c * p + i) * p + j;
+        if (SPLIT) {
+            const uint16_t* x = (const uint16_t*)xv;
+            out[t] = bf16_to_f32(x[src]) + bf16_to_f32(x[plane + src]);
+        } else {
+            out[t] = ((const float*)xv)[src];
+        }
     }
 }
 
@@ -585,9 +593,13 @@ extern "C" int ufm_unmap_channels(const float* chan, int B, int C, int h, int w,
     return UFM_OK;
 }
 
-extern "C" int ufm_pixel_shuffle_planar(const float* x, int B, int gh, int gw, int C, int p, float* out, void* stream) {
+extern "C" int ufm_pixel_shuffle_planar(const void* x, int in_dtype, int B, int gh, int gw, int C, int p, float* out, void* stream) {
     UFM_REQUIRE(x && out && B > 0 && gh > 0 && gw > 0 && C > 0 && p > 0, "ufm_pixel_shuffle_planar: bad args");
-    hipLaunchKernelGGL(pixel_shuffle_kernel, stream_grid((size_t)B * C * gh * p * gw * p), dim3(256), 0, (hipStream_t)stream, x, B, gh, gw, C, p, out);
+    UFM_REQUIRE(in_dtype == UFM_F32 || in_dtype == UFM_BF16X2, "ufm_pixel_shuffle_planar: bad in_dtype %d", in_dtype);
+    if (in_dtype == UFM_BF16X2)
+        hipLaunchKernelGGL(pixel_shuffle_kernel<1>, stream_grid((size_t)B * C * gh * p * gw * p), dim3(256), 0, (hipStream_t)stream, x, B, gh, gw, C, p, out);
+    else
+        hipLaunchKernelGGL(pixel_shuffle_kernel<0>, stream_grid((size_t)B * C * gh * p * gw * p), dim3(256), 0, (hipStream_t)stream, x, B, gh, gw, C, p, out);
     UFM_CHECK_LAUNCH("ufm_pixel_shuffle_planar");
     return UFM_OK;
 }

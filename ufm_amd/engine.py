@@ -103,6 +103,16 @@ class _Conv:
             self.w = _split_bf16(self.w)
 
 
+def _lin_as_conv(lin: nn.Linear, dev) -> _Conv:
+    """nn.Linear as the 1x1 convolution it is, packed for the bf16x3 kernel."""
+    conv = nn.Conv2d(lin.in_features, lin.out_features, kernel_size=1, bias=lin.bias is not None)
+    with torch.no_grad():
+        conv.weight.copy_(lin.weight.detach().float().cpu()[:, :, None, None])
+        if lin.bias is not None:
+            conv.bias.copy_(lin.bias.detach().float().cpu())
+    return _Conv(conv, dev, split=True)
+
+
 class _Head:
     def __init__(self, head: nn.Sequential, dev, split: bool = False):
         _C = lambda m, d: _Conv(m, d, split)  # noqa: E731
@@ -198,8 +208,16 @@ class Engine:
         self.refine = hasattr(m, "classification_head")
         if self.refine:
             ch = m.classification_head
-            self.cls_fc1 = _Lin(ch.mlp.fc1, dev, torch.float32)  # classification head runs in the fp32 island (ufm.py:921-965)
-            self.cls_fc2 = _Lin(ch.mlp.fc2, dev, torch.float32)
+            # the classification head runs inside the fp32 island (ufm.py:921-965; the comment at :949 says "autocast", the
+            # indentation says otherwise): exact-fp32 MFMA in "parity", the bf16x3 split form (a 1x1 convolution over the token
+            # rows) wherever the DPT heads use it
+            if self.head_split:
+                self.cls_fc1, self.cls_fc2 = _lin_as_conv(ch.mlp.fc1, dev), _lin_as_conv(ch.mlp.fc2, dev)
+                for c in (self.cls_fc1, self.cls_fc2):
+                    c.n = c.cout  # (the Linear's output width, as _Lin names it)
+            else:
+                self.cls_fc1 = _Lin(ch.mlp.fc1, dev, torch.float32)
+                self.cls_fc2 = _Lin(ch.mlp.fc2, dev, torch.float32)
             self.cls_out_dim = ch.output_dim
             self.cls_bias = _f32(m.classification_bias, dev)
             self.unet = None
@@ -281,7 +299,7 @@ class Engine:
             iv1 = (b * 2 * Np + p).reshape(-1)
             iv2 = (b * 2 * Np + Np + p).reshape(-1)
             mk = lambda t: t.to(torch.int32).to(self.dev)  # noqa: E731
-            self._tables[key] = dict(enc_v1=mk(v1), enc_all=mk(all_), enc_info=mk(info), info_v1=mk(iv1), info_v2=mk(iv2))
+            self._tables[key] = dict(enc_v1=mk(v1), enc_all=mk(all_), enc_info=mk(info), info_v1=mk(iv1), info_v2=mk(iv2), info_all=mk(torch.cat([iv1, iv2])))
         return self._tables[key]
 
     def _view_pe_table(self, Np: int) -> torch.Tensor:
@@ -603,8 +621,12 @@ class Engine:
         def on_enc(i, xx):
             nonlocal enc_first, lvl0
             if self.refine and i == self.enc_indices[0]:
-                enc_first = self.buf("enc_first", (B2 * Np, D))
-                hip.layernorm(xx, D, idx["enc_all"], B2 * Np, D, nw, nb, 1e-6, enc_first)
+                if self.head_split:  # straight into the classification head's split-format input, columns [0, D)
+                    enc_first = self.buf("cls_in_x2", (2, B2 * Np, D + Di), torch.bfloat16)
+                    hip.layernorm(xx, D, idx["enc_all"], B2 * Np, D, nw, nb, 1e-6, enc_first[0], ldo=D + Di, split=True)
+                else:
+                    enc_first = self.buf("enc_first", (B2 * Np, D))
+                    hip.layernorm(xx, D, idx["enc_all"], B2 * Np, D, nw, nb, 1e-6, enc_first)
             if i == self.enc_indices[-1]:
                 hip.layernorm(xx, D, idx["enc_info"], B * 2 * Np, D, nw, nb, 1e-6, enc_info)
                 lvl0 = self.level_ln(xx, D, idx["enc_v1"], B * Np, nw, nb, "lvl0")
@@ -668,22 +690,32 @@ class Engine:
                 out[tag] = self._head(hw, tag, levels, dims, B, gh, gw, H, W)
 
         if self.refine:  # ufm.py:949-1007
-            lvl3a = self.buf("lvl3_v1_f32", (B * Np, Di))
-            hip.layernorm(y, Di, idx["info_v1"], B * Np, Di, inw, inb, 1e-6, lvl3a)
-            lvl3b = self.buf("lvl3_v2", (B * Np, Di))
-            hip.layernorm(y, Di, idx["info_v2"], B * Np, Di, inw, inb, 1e-6, lvl3b)
             C1 = D + Di
-            cat = self.buf("cls_in", (B2 * Np, C1))
-            # torch.cat along channels == strided row copies: enc_first | info_final, views stacked on batch
-            hip.add_rows(enc_first, D, None, 0, cat, C1, 0, B2 * Np, D)
-            hip.add_rows(lvl3a, Di, None, 0, cat[:, D:], C1, 0, B * Np, Di)
-            hip.add_rows(lvl3b, Di, None, 0, cat[B * Np :, D:], C1, 0, B * Np, Di)
-            hidden = self.buf("cls_hid", (B2 * Np, self.cls_fc1.n))
-            self.linear(cat, self.cls_fc1, B2 * Np, hidden, act=hip.ACT_GELU)
-            tok = self.buf("cls_tok", (B2 * Np, self.cls_fc2.n))
-            self.linear(hidden, self.cls_fc2, B2 * Np, tok)
+            if self.head_split:
+                # torch.cat([enc_first | info_final], channels), views stacked on batch (ufm.py:955-964), built in the split
+                # format by the two LayerNorm launches themselves; the MLP is two 1x1 bf16x3 convolutions over the rows
+                cat = enc_first
+                hip.layernorm(y, Di, idx["info_all"], B2 * Np, Di, inw, inb, 1e-6, cat[0][:, D:], ldo=C1, split=True)
+                hidden = self.buf("cls_hid_x2", (2, B2 * Np, self.cls_fc1.n), torch.bfloat16)
+                self.conv(cat, 1, 1, B2 * Np, self.cls_fc1, hidden, act=hip.ACT_GELU)
+                tok = self.buf("cls_tok_x2", (2, B2 * Np, self.cls_fc2.n), torch.bfloat16)
+                self.conv(hidden, 1, 1, B2 * Np, self.cls_fc2, tok)
+            else:
+                lvl3a = self.buf("lvl3_v1_f32", (B * Np, Di))
+                hip.layernorm(y, Di, idx["info_v1"], B * Np, Di, inw, inb, 1e-6, lvl3a)
+                lvl3b = self.buf("lvl3_v2", (B * Np, Di))
+                hip.layernorm(y, Di, idx["info_v2"], B * Np, Di, inw, inb, 1e-6, lvl3b)
+                cat = self.buf("cls_in", (B2 * Np, C1))
+                # torch.cat along channels == strided row copies: enc_first | info_final, views stacked on batch
+                hip.add_rows(enc_first, D, None, 0, cat, C1, 0, B2 * Np, D)
+                hip.add_rows(lvl3a, Di, None, 0, cat[:, D:], C1, 0, B * Np, Di)
+                hip.add_rows(lvl3b, Di, None, 0, cat[B * Np :, D:], C1, 0, B * Np, Di)
+                hidden = self.buf("cls_hid", (B2 * Np, self.cls_fc1.n))
+                self.linear(cat, self.cls_fc1, B2 * Np, hidden, act=hip.ACT_GELU)
+                tok = self.buf("cls_tok", (B2 * Np, self.cls_fc2.n))
+                self.linear(hidden, self.cls_fc2, B2 * Np, tok)
             feats = torch.empty((B2, self.cls_out_dim, H, W), device=self.dev)
-            hip.pixel_shuffle_planar(tok, B2, gh, gw, self.cls_out_dim, self.P, feats)
+            hip.pixel_shuffle_planar(tok, B2, gh, gw, self.cls_out_dim, self.P, feats, split=self.head_split)
             if self.unet is not None:  # ufm.py:915-917, :967-983: one UNet pass per view, then the per-pixel combine
                 combined = torch.empty_like(feats)
                 for v in range(2):

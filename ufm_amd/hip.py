@@ -57,7 +57,7 @@ SIGNATURES = {
     "ufm_maxpool2x2_nhwc": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
     "ufm_resize_nearest_nhwc": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp],
     "ufm_unet_combine": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],
-    "ufm_pixel_shuffle_planar": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "ufm_pixel_shuffle_planar": [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "ufm_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
     "ufm_add_f32": [_vp, _vp, _vp, _i64, _vp],
 }
@@ -296,9 +296,10 @@ def unet_combine(cls, unet, N, HW, ldu, w1, b1, w2, b2, method, out):
     _check(lib().ufm_unet_combine(_p(cls), _p(unet), _fmt(unet), N, HW, ldu, _p(w1), _p(b1), _p(w2), _p(b2), method, _p(out), _stream()), "ufm_unet_combine")
 
 
-def pixel_shuffle_planar(x, B, gh, gw, Cc, p, out):
+def pixel_shuffle_planar(x, B, gh, gw, Cc, p, out, split=False):
+    """split=True: `x` is a (2, rows, C*p*p) bf16 tensor in the UFM_BF16X2 format."""
     _t("ufm_pixel_shuffle_planar", 8.0 * B * gh * gw * p * p * Cc)
-    _check(lib().ufm_pixel_shuffle_planar(_p(x), B, gh, gw, Cc, p, _p(out), _stream()), "ufm_pixel_shuffle_planar")
+    _check(lib().ufm_pixel_shuffle_planar(_p(x), BF16X2 if split else F32, B, gh, gw, Cc, p, _p(out), _stream()), "ufm_pixel_shuffle_planar")
 
 
 def cast_bf16(x, out):
