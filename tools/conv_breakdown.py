@@ -6,11 +6,12 @@ import ufm_amd
 from ufm_amd import hip
 from ufm_amd.modules import init_weights_
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-m = ufm_amd.UniFlowMatchConfidence(**ufm_amd.ufm_base_config()).eval()
+RES = int(sys.argv[2]) if len(sys.argv) > 2 else 518
+m = ufm_amd.UniFlowMatchConfidence(**ufm_amd.ufm_base_config(resolution_wh=(RES, RES))).eval()
 init_weights_(m, 0)
 m = m.to("cuda")
-src = torch.randint(0, 256, (B, 518, 518, 3), dtype=torch.uint8).cuda()
-tgt = torch.randint(0, 256, (B, 518, 518, 3), dtype=torch.uint8).cuda()
+src = torch.randint(0, 256, (B, RES, RES, 3), dtype=torch.uint8).cuda()
+tgt = torch.randint(0, 256, (B, RES, RES, 3), dtype=torch.uint8).cuda()
 for _ in range(2):
     m.predict_correspondences_batched(src, tgt)
 hip.TIMER = hip.KernelTimer()
