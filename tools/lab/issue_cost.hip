@@ -13,7 +13,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define REP 64
 
 // VARIANT bits: 1 = MFMA (AGPR acc), 2 = MFMA with VGPR C/D instead, 4 = 2 x v_exp, 8 = 2 x v_add (two chains),
-// 16 = v_cvt_pk, 32 = one global_load_lds per 4 gaps, 64 = A and B operands from AGPRs, 128: one ds_read_b128 per gap
+// 16 = v_cvt_pk, 32 = one global_load_lds per 4 gaps, 64 = A and B operands from AGPRs, 128: one ds_read_b128 per gap,
+// 256: a further ds_read_b128 every second gap (1.5 reads per gap: the 8-wave x 32-row attention layout's ratio)
 template <int V>
 __global__ __launch_bounds__(1024) void k(const char* g, unsigned long long* out, float* sink) {
     __shared__ __attribute__((aligned(16))) char smem[64 * 1024];
@@ -23,7 +24,7 @@ __global__ __launch_bounds__(1024) void k(const char* g, unsigned long long* out
     bf16x8 aa = a, ab = b;
     float x0 = lane * 0.01f, x1 = lane * 0.02f, s0 = 0.f, s1 = 0.f, e0 = 0.f, e1 = 0.f;
     unsigned pk = 0;
-    bf16x8 ld = {0}, ldv[8];
+    bf16x8 ld = {0}, ldv[8], ldw[4];
     const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)((__attribute__((address_space(3))) void*)(smem)) + (threadIdx.x >> 6) * 1024);
     unsigned long long t0, t1;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
@@ -44,6 +45,7 @@ __global__ __launch_bounds__(1024) void k(const char* g, unsigned long long* out
             if ((V & 32) && (gp & 3) == 1)
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"((unsigned)(lane * 16 + (r & 63) * 1024)), "s"(g) : "memory");
             if (V & 128) asm volatile("ds_read_b128 %0, %1" : "=v"(ldv[gp]) : "v"((unsigned)(lane * 16 + gp * 1024)));
+            if ((V & 256) && (gp & 1)) asm volatile("ds_read_b128 %0, %1" : "=v"(ldw[gp >> 1]) : "v"((unsigned)(lane * 16 + gp * 1024 + 8192)));
             __builtin_amdgcn_sched_barrier(0);
         }
         if (V & 32) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -51,6 +53,9 @@ __global__ __launch_bounds__(1024) void k(const char* g, unsigned long long* out
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int q = 0; q < 8; ++q) ld[0] ^= ldv[q][0];
+            if (V & 256)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ld[0] ^= ldw[q][0];
         }
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
@@ -98,6 +103,9 @@ int main() {
         R(2 | 4 | 8 | 16, "mfma(V acc) + 2 exp + 2 add + cvt");
         R(4, "2 exp");
         R(8, "2 add");
+        R(1 | 4 | 8 | 16 | 128, "mfma(A) + 2 exp + 2 add + cvt + 1 ds_read_b128");
+        R(1 | 4 | 8 | 16 | 128 | 256, "mfma(A) + 2 exp + 2 add + cvt + 1.5 ds_read_b128");
+        R(1 | 4 | 8 | 16 | 32 | 128 | 256, "mfma(A) + 2 exp + 2 add + cvt + 1.5 ds_read + glds/4 gaps");
     }
     g_threads = 256;
     printf("-- 1 wave per SIMD --\n");
@@ -118,6 +126,7 @@ int main() {
     R(2 | 4 | 8 | 16, "mfma(V acc, V ops) + 2 exp + 2 add + cvt");
     R(1 | 4 | 8 | 16 | 128, "mfma(A) + 2 exp + 2 add + cvt + ds_read_b128");
     R(1 | 4 | 8 | 16 | 32, "mfma(A) + 2 exp + 2 add + cvt + glds/4 gaps");
+    R(1 | 4 | 8 | 16 | 32 | 128, "mfma(A) + 2 exp + 2 add + cvt + ds_read + glds/4 gaps");
     R(32, "glds/4 gaps alone");
     R(1 | 32, "mfma(A) + glds/4 gaps");
     return 0;
