@@ -5,11 +5,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from ufm_amd import hip
 lib = hip.lib()
 torch.manual_seed(0)
-for b, n, h in ((2, 1370, 16), (1, 2738, 12), (4, 1370, 16), (2, 2738, 12), (6, 1370, 16), (3, 2738, 12), (8, 1370, 16), (4, 2738, 12)):
+for b, n, h in ((2, 1370, 16), (1, 2738, 12), (8, 1370, 16), (4, 2738, 12), (16, 1370, 16), (8, 2738, 12), (2, 10954, 12)):
     qkv = torch.randn(b * n, 3 * h * 64, device="cuda").bfloat16()
     o = torch.empty(b * n, h * 64, device="cuda", dtype=torch.bfloat16)
     r = []
-    for v in (0, 1):
+    for v in (0, 1, 2):
         lib.ufm_debug_set_attn_variant(v)
         for _ in range(5): hip.attention(qkv, o, b, n, h, 0.0)
         torch.cuda.synchronize()
