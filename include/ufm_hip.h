@@ -197,6 +197,8 @@ int ufm_conv2d_nhwc_bf16x3(const uint16_t* in, int B, int H, int W, int Cin, con
                            int Cout, int KH, int KW, int stride, int pad, int relu_in,
                            const float* bias, int act, const uint16_t* res1, const uint16_t* res2,
                            int shuffle, uint16_t* out, uint16_t* out_relu, const uint16_t* zero_page,
+                           int passes /* 3 = bf16x3; 1 = hi planes only: a plain bf16 convolution with fp32 accumulation,
+                                         the arithmetic bf16 autocast gives the reference's UNet (ufm.py:915-917) */,
                            void* stream);
 
 /* Bilinear resize, align_corners=True, NHWC fp32 ([U] FeatureFusionBlock x2 upsample,

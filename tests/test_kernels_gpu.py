@@ -624,6 +624,38 @@ def test_conv2d_bf16x3(hip, B, H, W, Cin, Cout, k, stride, pad, relu_in, act, nr
 
 
 @pytest.mark.parametrize(
+    "B,H,W,Cin,Cout,k,stride,pad,relu_in,act",
+    [
+        (1, 37, 37, 64, 128, 3, 1, 1, True, 0),     # 64x64 tiles
+        (4, 128, 128, 32, 128, 3, 1, 1, False, 2),  # 128x128 tiles
+        (4, 128, 128, 64, 64, 3, 1, 1, False, 2),   # 128x64 tiles
+        (2, 64, 64, 128, 96, 1, 1, 0, False, 0),    # 128x32 tiles, 1x1
+        (2, 9, 11, 96, 1024, 1, 1, 0, False, 0),    # Cout = 1024 (the 8-phase kernel is never used for passes = 1)
+    ],
+)
+def test_conv2d_single_pass_is_a_bf16_convolution(hip, B, H, W, Cin, Cout, k, stride, pad, relu_in, act):
+    """passes = 1 (the UNet under the reference's bf16 autocast, ufm.py:915-917): only the hi planes of the split operands
+    enter the MFMAs, i.e. conv(bf16(x), bf16(w)) with fp32 accumulation -- compared with that statement in fp64; the lo planes
+    of input and weight (filled with junk here) must not matter."""
+    x = rnd(B, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5)
+    b = rnd(Cout, seed=3, scale=0.1)
+    xb, wb = bf16r(x), bf16r(w)
+    ref = F.conv2d((F.relu(xb) if relu_in else xb).double(), wb.double(), b.double(), stride=stride, padding=pad)
+    if act == 2:
+        ref = F.relu(ref)
+    Ho, Wo = ref.shape[2:]
+    xs, ws = split(nhwc(x)), split(w.permute(0, 2, 3, 1).contiguous())
+    xs[1] = rnd(*xs[1].shape, seed=7).to(torch.bfloat16)  # junk in the lo planes
+    ws[1] = rnd(*ws[1].shape, seed=8).to(torch.bfloat16)
+    out = torch.zeros(2, B, Ho, Wo, Cout, device=DEV, dtype=torch.bfloat16)
+    hip.conv2d_x3(xs.to(DEV), B, H, W, Cin, ws.to(DEV), Cout, k, k, stride, pad, out, torch.zeros(256, device=DEV), relu_in=relu_in, bias=b.to(DEV), act=act, passes=1)
+    got = unsplit(out.cpu()).permute(0, 3, 1, 2).double()
+    err = (got - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err  # fp32 accumulation order + the split store (2^-17)
+
+
+@pytest.mark.parametrize(
     "B,H,W,Cin,Cout,k,stride,pad,relu_in,act,nres,shuffle",
     [
         (2, 37, 37, 64, 256, 3, 1, 1, True, 0, 2, 0),     # ragged M (2738 px), both residuals, ReLU on the input

@@ -544,11 +544,13 @@ def test_covariance_unmap_against_reference_golden(env, golden_dir, name):
     assert np.abs(cov - g["cov_out"]).max() <= 1e-5 * max(1.0, float(np.abs(g["cov_out"]).max()))
 
 
-@pytest.mark.parametrize("numerics", ["parity", "fast"])
+@pytest.mark.parametrize("numerics", ["parity", "parity_x3heads", "fast"])
 def test_unet_forward_against_reference_golden(env, golden_dir, numerics):
     """R5, pinned: Engine._unet (conv kernels + max-pool / nearest / concat kernels) vs the output of the reference's own
     UNet class (tests/golden/unet_full_odd.npz: features [64,128,256,512], 42x70 input: 42->21->10->5->2 with the nearest
-    fix-up of unet_encoder.py:66-67 at two levels).  Same weights by the same seeded initialiser."""
+    fix-up of unet_encoder.py:66-67 at two levels).  Same weights by the same seeded initialiser.  "parity" = fp32 MFMA,
+    "parity_x3heads" = bf16x3; "fast" = plain bf16 operands with fp32 accumulation, the arithmetic the reference's own
+    autocast policy gives this module (ufm.py:915-917 is outside the fp32 island) -- bounded at bf16 size."""
     ufm_amd, R = env
     from ufm_amd import hip
 
@@ -572,7 +574,8 @@ def test_unet_forward_against_reference_golden(env, golden_dir, numerics):
     got = got[..., :16].permute(0, 3, 1, 2).cpu().numpy()
     err = np.abs(got - g["y"]).max()
     print(f"UNet vs reference golden [{numerics}]: max-abs {err:.3g} (range {np.abs(g['y']).max():.3g})")
-    assert err <= 1e-3 * max(1.0, float(np.abs(g["y"]).max()))
+    tol = 2e-2 if numerics == "fast" else 1e-3  # measured: fast 6e-3 on a range of 0.9 (18 bf16 convolutions deep)
+    assert err <= tol * max(1.0, float(np.abs(g["y"]).max()))
 
 
 @pytest.mark.parametrize("method", ["conv", "modulate"])

@@ -26,8 +26,12 @@ constexpr int BK = 32;
 // other's DMA latency (big grids).  NS = 4 (BN >= 64): counted s_waitcnt vmcnt + raw s_barrier, two K-tiles stay in flight
 // across every barrier -- used for the 64x64 tile on small grids with long K loops (the 19^2 layers: 46-184 blocks, K up
 // to 6912), where nothing else on the CU covers the ~0.5 us of each K-step's DMA.  Same arithmetic order: results are bit-identical.
-template <int BM, int BN, int NS>
+// PASSES = 3: hi*hi + hi*lo + lo*hi.  PASSES = 1: the hi planes only -- exactly a bf16 convolution with fp32 accumulation
+// (operands rounded to bf16, what torch.autocast(bfloat16) gives the reference's UNet, ufm.py:915-917): the lo planes are
+// neither staged nor read, one MFMA per fragment pair and K-tile.  Output format and epilogue are the same.
+template <int BM, int BN, int NS, int PASSES = 3>
 __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void conv_x3_kernel(ConvX3Args p) {
+    static_assert(PASSES == 3 || PASSES == 1, "PASSES");
     constexpr int WN = BN >= 64 ? 2 : 1, WM = 4 / WN;
     constexpr int A_RPW = BM / 4, A_PIECES = A_RPW / 16;  // A rows / DMA pieces per wave and plane
     constexpr int TM = (BM / WM) / 16, TN = (BN / WN) / 16;
@@ -36,7 +40,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void conv_x3_kernel(ConvX3Arg
     constexpr int W_ROWS_PER_WAVE = BN / 4;                             // 32 / 16 / 8
     constexpr int W_PIECES = W_ROWS_PER_WAVE >= 16 ? W_ROWS_PER_WAVE / 16 : 1;
     static_assert(NS == 2 || BN >= 64, "the deep ring needs the same DMA piece count in every wave");
-    constexpr int PIECES = 2 * (A_PIECES + W_PIECES);  // global_load_lds per wave and K-tile (BN >= 64)
+    constexpr int PIECES = (PASSES == 3 ? 2 : 1) * (A_PIECES + W_PIECES);  // global_load_lds per wave and K-tile (BN >= 64)
     __shared__ __attribute__((aligned(16))) char smem[NS * STAGE_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void conv_x3_kernel(ConvX3Arg
             const uint16_t* src = ok ? p.in + (a_img[i] + (size_t)iy * p.W + ix) * p.Cin + c0 + a_chunk[i] : p.zero + a_chunk[i];
             const uint16_t* src_lo = ok ? src + p.in_plane : src;
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(sa + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src_lo), LDS_PTR(sa + A_PLANE + i * 1024), 16, 0, 0);
+            if (PASSES == 3) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src_lo), LDS_PTR(sa + A_PLANE + i * 1024), 16, 0, 0);
         }
         if (w_active) {
             char* sb = smem + buf * STAGE_BYTES + 2 * A_PLANE + w_lds_row0 * 64;
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void conv_x3_kernel(ConvX3Arg
             for (int i = 0; i < W_PIECES; ++i) {
                 const uint16_t* src = gw[i] + koff;
                 __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(sb + i * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + p.w_plane), LDS_PTR(sb + W_PLANE + i * 1024), 16, 0, 0);
+                if (PASSES == 3) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + p.w_plane), LDS_PTR(sb + W_PLANE + i * 1024), 16, 0, 0);
             }
         }
     };
@@ -152,24 +156,26 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void conv_x3_kernel(ConvX3Arg
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             ah[i] = *(const bf16x8*)(s + a_off[i]);
-            al[i] = *(const bf16x8*)(s + A_PLANE + a_off[i]);
+            if (PASSES == 3) al[i] = *(const bf16x8*)(s + A_PLANE + a_off[i]);
             if (p.relu_in) {
                 const bf16x8 neg = ah[i] >> 15;  // 0xFFFF where hi < 0 (sign of hi decides for both halves)
                 ah[i] &= ~neg;
-                al[i] &= ~neg;
+                if (PASSES == 3) al[i] &= ~neg;
             }
         }
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
             wh[i] = *(const bf16x8*)(s + w_off[i]);
-            wl[i] = *(const bf16x8*)(s + W_PLANE + w_off[i]);
+            if (PASSES == 3) wl[i] = *(const bf16x8*)(s + W_PLANE + w_off[i]);
         }
 #pragma unroll
         for (int n = 0; n < TN; ++n)
 #pragma unroll
             for (int m = 0; m < TM; ++m) {
-                acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[n], ah[m], acc[n][m], 0, 0, 0);
-                acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], al[m], acc[n][m], 0, 0, 0);
+                if (PASSES == 3) {
+                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[n], ah[m], acc[n][m], 0, 0, 0);
+                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], al[m], acc[n][m], 0, 0, 0);
+                }
                 acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n], ah[m], acc[n][m], 0, 0, 0);
             }
     }
@@ -192,8 +198,9 @@ extern "C" int ufm_debug_set_conv_variant(int v) {
 extern "C" int ufm_conv2d_nhwc_bf16x3(const uint16_t* in, int B, int H, int W, int Cin, const uint16_t* weight, int Cout,
                                       int KH, int KW, int stride, int pad, int relu_in, const float* bias, int act,
                                       const uint16_t* res1, const uint16_t* res2, int shuffle, uint16_t* out,
-                                      uint16_t* out_relu, const uint16_t* zero_page, void* stream) {
+                                      uint16_t* out_relu, const uint16_t* zero_page, int passes, void* stream) {
     UFM_REQUIRE(in && weight && out && zero_page, "ufm_conv2d_nhwc_bf16x3: null pointer");
+    UFM_REQUIRE(passes == 3 || passes == 1, "ufm_conv2d_nhwc_bf16x3: passes=%d must be 3 (bf16x3) or 1 (plain bf16)", passes);
     UFM_REQUIRE(B > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, "ufm_conv2d_nhwc_bf16x3: bad geometry");
     UFM_REQUIRE(Cin % BK == 0 && Cin > 0, "ufm_conv2d_nhwc_bf16x3: Cin=%d must be a multiple of %d", Cin, BK);
     UFM_REQUIRE(Cout % 32 == 0 && Cout > 0, "ufm_conv2d_nhwc_bf16x3: Cout=%d must be a multiple of 32", Cout);
@@ -223,6 +230,17 @@ extern "C" int ufm_conv2d_nhwc_bf16x3(const uint16_t* in, int B, int H, int W, i
         const long long blocks128 = (long long)ntm * (Cout % 128 == 0 ? Cout / 128 : Cout % 64 == 0 ? Cout / 64 : Cout / 32);
         // small grid: 64x64 tiles, several co-resident blocks per CU.  Threshold from an end-to-end sweep (400 / 200 / 100:
         // 189.6 / 196.6 / 197.2 pairs/s with two micro-batches): at 128..400 blocks the 128-row tiles win
+        if (passes == 1) {  // plain bf16: the two-stage kernels only
+            if (Cout % 64 == 0 && blocks128 < 128)
+                hipLaunchKernelGGL((conv_x3_kernel<64, 64, 2, 1>), dim3((unsigned)(((Mq + 63) / 64) * (Cout / 64))), dim3(256), 0, (hipStream_t)stream, q);
+            else if (Cout % 128 == 0)
+                hipLaunchKernelGGL((conv_x3_kernel<128, 128, 2, 1>), dim3(ntm * (Cout / 128)), dim3(256), 0, (hipStream_t)stream, q);
+            else if (Cout % 64 == 0)
+                hipLaunchKernelGGL((conv_x3_kernel<128, 64, 2, 1>), dim3(ntm * (Cout / 64)), dim3(256), 0, (hipStream_t)stream, q);
+            else
+                hipLaunchKernelGGL((conv_x3_kernel<128, 32, 2, 1>), dim3(ntm * (Cout / 32)), dim3(256), 0, (hipStream_t)stream, q);
+            return;
+        }
         if (Cout % 64 == 0 && blocks128 < 128) {
             const unsigned grid = (unsigned)(((Mq + 63) / 64) * (Cout / 64));
             // measured per layer (tools/conv_breakdown.py): the deep ring pays on long K loops only (19^2 768->256: 138 -> 102 us;
@@ -243,7 +261,9 @@ extern "C" int ufm_conv2d_nhwc_bf16x3(const uint16_t* in, int B, int H, int W, i
     const int tile_n = 256, tile_m = 256;
     const bool ok8 = Cout % 256 == 0 && KH * KW * (Cin / 32) >= 2 && p.in_plane < (1ll << 31) && p.w_plane < (1ll << 31);
     const long long t8 = ((M + tile_m - 1) / tile_m) * (Cout / tile_n);
-    if (ok8 && g_conv_variant == 2) {
+    if (passes == 1) {
+        launch128(p);
+    } else if (ok8 && g_conv_variant == 2) {
         ufm_launch_conv_x3_8ph(p, (hipStream_t)stream);
     } else if (ok8 && g_conv_variant == 0 && t8 >= 256) {  // (variants 1 and 3 never take this branch)
         const long long full = t8 / 256;                                // whole rounds of the 8-phase kernel

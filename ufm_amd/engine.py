@@ -230,6 +230,12 @@ class Engine:
                     ups=[(_Conv(u.ups[k], dev, sp), dc(u.ups[k + 1])) for k in range(0, len(u.ups), 2)],
                     final=_Conv(u.final_conv, dev, sp, cout_pad=32),
                 )
+                if self.numerics == "fast":
+                    # the reference runs the UNet OUTSIDE its fp32 island (ufm.py:915-917), i.e. under the bf16 autocast of
+                    # base.py:273: plain bf16 operands, fp32 accumulation -- the hi planes of the split format, one MFMA pass
+                    for c in [c for pair in self.unet["downs"] for c in pair] + list(self.unet["bottleneck"]) + \
+                             [c for ct, pair in self.unet["ups"] for c in (ct,) + tuple(pair)] + [self.unet["final"]]:
+                        c.passes = 1
                 assert u.out_channels == 16 and self.cls_out_dim == 16, "the combine step is built for 16 + 16 feature channels (ufm.py:818-825)"
                 self.unet_method = 0 if m.feature_combine_method == "conv" else 1
                 self.unet_w1 = _f32(m.conv1.weight.reshape(m.conv1.weight.shape[0], -1), dev)
@@ -319,7 +325,8 @@ class Engine:
 
     def conv(self, x, B, H, W, c: _Conv, out, *, relu_in=False, act=hip.ACT_NONE, res1=None, res2=None, out_relu=None):
         if c.w.dtype == torch.bfloat16:
-            hip.conv2d_x3(x, B, H, W, c.cin, c.w, c.cout, c.k, c.k, c.stride, c.pad, out, self.zero, relu_in=relu_in, bias=c.b, act=act, res1=res1, res2=res2, shuffle=c.shuffle, out_relu=out_relu)
+            hip.conv2d_x3(x, B, H, W, c.cin, c.w, c.cout, c.k, c.k, c.stride, c.pad, out, self.zero, relu_in=relu_in, bias=c.b, act=act, res1=res1, res2=res2, shuffle=c.shuffle, out_relu=out_relu,
+                          passes=getattr(c, "passes", 3))
         else:
             assert out_relu is None
             hip.conv2d(x, B, H, W, c.cin, c.w, c.cout, c.k, c.k, c.stride, c.pad, out, self.zero, relu_in=relu_in, bias=c.b, act=act, res1=res1, res2=res2, shuffle=c.shuffle)

@@ -45,7 +45,7 @@ SIGNATURES = {
     "ufm_attention_f32": [_vp, _vp, _i, _i, _i, _f, _vp],
     "ufm_debug_attention_stamps": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "ufm_conv2d_nhwc_f32": [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp],
-    "ufm_conv2d_nhwc_bf16x3": [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp],
+    "ufm_conv2d_nhwc_bf16x3": [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp],
     "ufm_upsample_bilinear_nhwc": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp],
     "ufm_head_tail": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _ip, _fp3, _fp3, _vp, _vp, _vp],
     "ufm_adaptor_covariance2d": [_vp, _i, _i, _vp, _vp, _vp, _vp],
@@ -215,12 +215,13 @@ def conv2d(x, B, H, W, Cin, weight, Cout, KH, KW, stride, pad, out, zero_page, *
     )
 
 
-def conv2d_x3(x, B, H, W, Cin, weight, Cout, KH, KW, stride, pad, out, zero_page, *, relu_in=False, bias=None, act=ACT_NONE, res1=None, res2=None, shuffle=0, out_relu=None):
-    """bf16x3 split-precision conv; x / weight / res / out are (2, ...) bf16 tensors (UFM_BF16X2)."""
+def conv2d_x3(x, B, H, W, Cin, weight, Cout, KH, KW, stride, pad, out, zero_page, *, relu_in=False, bias=None, act=ACT_NONE, res1=None, res2=None, shuffle=0, out_relu=None, passes=3):
+    """bf16x3 split-precision conv; x / weight / res / out are (2, ...) bf16 tensors (UFM_BF16X2).
+    passes=1: the hi planes only (a plain bf16 convolution with fp32 accumulation), same operand and output format."""
     Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
-    _t("ufm_conv2d_nhwc_bf16x3", 2.0 * B * Ho * Wo * Cout * KH * KW * Cin)
+    _t("ufm_conv2d_nhwc_bf16x3" if passes == 3 else "ufm_conv2d_nhwc_bf16x1", 2.0 * B * Ho * Wo * Cout * KH * KW * Cin)
     _check(
-        lib().ufm_conv2d_nhwc_bf16x3(_p(x), B, H, W, Cin, _p(weight), Cout, KH, KW, stride, pad, int(relu_in), _p(bias), act, _p(res1), _p(res2), shuffle, _p(out), _p(out_relu), _p(zero_page), _stream()),
+        lib().ufm_conv2d_nhwc_bf16x3(_p(x), B, H, W, Cin, _p(weight), Cout, KH, KW, stride, pad, int(relu_in), _p(bias), act, _p(res1), _p(res2), shuffle, _p(out), _p(out_relu), _p(zero_page), passes, _stream()),
         "ufm_conv2d_nhwc_bf16x3",
     )
 
