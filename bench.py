@@ -359,6 +359,7 @@ def main():
     if rank == 0:
         print(json.dumps(line))
     if use_dist:
+        dist.barrier()  # rank 0's single-rank extras (kernel timing, latency) are done: all ranks leave together
         dist.destroy_process_group()
 
 
