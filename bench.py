@@ -323,7 +323,7 @@ def main():
         }
 
     # ---- single-pair latency (BASELINE metric: "pairs/s + p50 latency"): wall clock of one synchronous call ----
-    if rank == 0 and not args.no_latency:
+    if rank == 0 and world == 1 and not args.no_latency:  # (a one-GPU measurement; at N > 1 the graph capture would run beside live RCCL work)
         s1d, t1d = src[:1].contiguous(), tgt[:1].contiguous()
         eager = p50_ms(lambda: model.predict_correspondences_batched(s1d, t1d), 20, 3)
         lat = {"eager_p50": eager, "iters": 20, "batch": 1}
