@@ -19,6 +19,8 @@ Rank 0 prints ONE JSON line.  Extra objects:
   cpu_baseline  the fp32 CPU oracle (a port; the reference's own CPU path cannot run, its
                 arithmetic lives in an absent package) timed on this box's host cores on a
                 bounded sample (rank 0, N=1 only).
+  precise_mode  the SAME workload in numerics "precise" (bf16x3 split precision for every contraction: the 1e-3 px gate on
+                the bf16 matrix cores): pairs/s, ms/step, its flow max-abs vs the oracle, per-kernel durations (rank 0, N=1).
   parity_mode   the SAME workload in numerics "parity" (exact-fp32 MFMA everywhere, the mode that meets the
                 1e-3 px gate): pairs/s, ms/step and its flow max-abs vs the oracle (rank 0, N=1 only).
   latency_b1_ms single-pair p50 latency (BASELINE metric "pairs/s + p50 latency"): eager launches and
@@ -40,6 +42,12 @@ PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip t
 PEAK_F32_TFLOPS = 157.3    # f32-input MFMA
 PEAK_BF16X3_TFLOPS = PEAK_BF16_TFLOPS / 3.0  # split-precision conv: 3 bf16 MFMAs per algorithmic MAC
 PEAK_HBM_GBS = 8000.0
+
+
+# MFMA-bound kernel families and the dense peak their operand format allows
+MFMA_PEAKS = {"ufm_gemm_bf16": PEAK_BF16_TFLOPS, "ufm_attention_bf16": PEAK_BF16_TFLOPS, "ufm_conv2d_nhwc_f32": PEAK_F32_TFLOPS,
+              "ufm_attention_f32": PEAK_F32_TFLOPS, "ufm_conv2d_nhwc_bf16x3": PEAK_BF16X3_TFLOPS, "ufm_dpt_tail_fused": PEAK_BF16X3_TFLOPS,
+              "ufm_gemm_bf16x3": PEAK_BF16X3_TFLOPS, "ufm_attention_bf16x3": PEAK_BF16X3_TFLOPS}
 
 
 def host_cores() -> int:
@@ -89,10 +97,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8, help="pairs per GPU per step")
     ap.add_argument("--res", type=int, default=518)
-    ap.add_argument("--numerics", default="fast", choices=["fast", "parity"])
+    ap.add_argument("--numerics", default="fast", choices=["fast", "precise", "parity"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the extra numerics='parity' timing of the same workload")
+    ap.add_argument("--no-precise-mode", action="store_true", help="skip the extra numerics='precise' timing of the same workload")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-pair latency measurement")
     ap.add_argument("--gemm-variant", type=int, default=0, help="tuning hook: ufm_debug_set_gemm_variant (0 = auto)")
     ap.add_argument("--attn-variant", type=int, default=0, help="tuning hook: ufm_debug_set_attn_variant (0 = default)")
@@ -200,7 +209,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "bf16" if args.numerics == "fast" else "f32",
+        "dtype": {"fast": "bf16", "precise": "bf16x3", "parity": "f32"}[args.numerics],
         "data": "synthetic",
         "config": {
             "workload": f"UFM-Base (DINOv2 ViT-L/14 + 12x768 joint-attention + 2 DPT heads), random-init weights, "
@@ -208,7 +217,9 @@ def main():
             "pairs_per_gpu": B,
             "global_batch": world * B,
             "resolution": res,
-            "numerics": f"{args.numerics}: " + ("bf16 MFMA trunk (fp32 accumulate/residual/LN/softmax stats), DPT heads in bf16x3 split precision (~2^-17 rel., fp32 accumulate)" if args.numerics == "fast" else "fp32 MFMA everywhere"),
+            "numerics": f"{args.numerics}: " + {"fast": "bf16 MFMA trunk (fp32 accumulate/residual/LN/softmax stats), DPT heads in bf16x3 split precision (~2^-17 rel., fp32 accumulate)",
+                                                 "precise": "bf16x3 split precision (hi*hi + hi*lo + lo*hi, fp32 accumulate) for every contraction: trunk GEMMs, attention, heads",
+                                                 "parity": "fp32 MFMA everywhere"}[args.numerics],
             "parallelism": f"dp{world} (pair-batch split; one async double-buffered RCCL all_gather of the results per step, ufm_amd.dist.ShardedPredictor)",
             "micro_batches_per_gpu": args.micro_batches,
         },
@@ -239,8 +250,8 @@ def main():
         for name, d in summ.items():
             work = sum(m for m in d["metas"] if m)
             entry = {"launches": d["launches"], "ms_per_step": d["ms"], "avg_launch_us": 1e3 * d["ms"] / d["launches"]}
-            if name in ("ufm_gemm_bf16", "ufm_attention_bf16", "ufm_conv2d_nhwc_f32", "ufm_conv2d_nhwc_bf16x3", "ufm_attention_f32", "ufm_dpt_tail_fused"):
-                peak = {"ufm_conv2d_nhwc_f32": PEAK_F32_TFLOPS, "ufm_attention_f32": PEAK_F32_TFLOPS, "ufm_conv2d_nhwc_bf16x3": PEAK_BF16X3_TFLOPS, "ufm_dpt_tail_fused": PEAK_BF16X3_TFLOPS}.get(name, PEAK_BF16_TFLOPS)
+            if name in MFMA_PEAKS:
+                peak = MFMA_PEAKS[name]
                 entry.update(bound="mfma", algorithmic_gflop=work / 1e9, achieved=work / (d["ms"] * 1e-3) / 1e12, peak=peak, unit="TFLOP/s")
                 entry["frac"] = entry["achieved"] / peak
             elif work:
@@ -272,8 +283,9 @@ def main():
             "traffic": d.get("traffic"), "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
             "avg_launch_us": d["avg_launch_us"], "algorithmic_gflop_per_launch": d["algorithmic_gflop"] / d["launches"],
         }
-        if "ufm_attention_bf16" in kernels:
-            a = kernels["ufm_attention_bf16"]
+        attn_name = next((k for k in ("ufm_attention_bf16", "ufm_attention_bf16x3", "ufm_attention_f32") if k in kernels), None)
+        if attn_name:
+            a = kernels[attn_name]
             line["attention"] = {"achieved": a["achieved"], "peak": a["peak"], "unit": "TFLOP/s", "frac": a["frac"], "ms_per_step": a["ms_per_step"]}
         line["kernels"] = kernels
         line["instrumented_step_ms"] = sum(v["ms_per_step"] for v in kernels.values())
@@ -335,6 +347,41 @@ def main():
         except Exception as exc:  # reported, not fatal: the eager number stands on its own
             lat["graph_error"] = repr(exc)[:200]
         line["latency_b1_ms"] = lat
+
+    # ---- the same workload in numerics "precise" (bf16x3 split precision everywhere: the 1e-3 px gate on the bf16 matrix cores) ----
+    if rank == 0 and world == 1 and args.numerics == "fast" and not args.no_precise_mode:
+        model.set_numerics("precise")
+        model.engine().micro_batches = args.micro_batches
+        for _ in range(2):
+            model.predict_correspondences_batched(src, tgt)
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        for _ in range(5):
+            model.predict_correspondences_batched(src, tgt)
+        torch.cuda.synchronize()
+        pre_s = (time.perf_counter() - c0) / 5
+        pm = {"value": B / pre_s, "unit": "pairs/s", "ms_per_step": 1e3 * pre_s, "steps": 5, "dtype": "bf16x3",
+              "numerics": "precise: hi*hi + hi*lo + lo*hi on the bf16 matrix cores for every contraction (trunk GEMMs, attention, heads), fp32 accumulate / residual / LN / softmax statistics"}
+        if ref_oracle is not None:
+            gotp = model.predict_correspondences_batched(src[:1], tgt[:1])
+            pm["flow_max_abs"] = float((gotp.flow.flow_output.cpu() - ref_oracle.flow.flow_output).abs().max())
+            pm["covis_max_abs"] = float((gotp.covisibility.mask.cpu() - ref_oracle.covisibility.mask).abs().max())
+        if not args.no_kernel_timing:
+            hip.TIMER = hip.KernelTimer()
+            model.predict_correspondences_batched(src, tgt)
+            summ = hip.TIMER.summary()
+            hip.TIMER = None
+            pk = {}
+            for name, d in summ.items():
+                if name in MFMA_PEAKS:
+                    work = sum(m for m in d["metas"] if m)
+                    pk[name] = {"launches": d["launches"], "ms_per_step": d["ms"], "achieved": work / (d["ms"] * 1e-3) / 1e12, "peak": MFMA_PEAKS[name],
+                                "unit": "TFLOP/s (algorithmic)", "frac": work / (d["ms"] * 1e-3) / 1e12 / MFMA_PEAKS[name]}
+                else:
+                    pk[name] = {"launches": d["launches"], "ms_per_step": d["ms"]}
+            pm["kernels"] = pk
+        line["precise_mode"] = pm
+        model.set_numerics("fast")
 
     # ---- the same workload in numerics "parity" (exact-fp32 MFMA everywhere: the mode that meets the 1e-3 px gate) ----
     if rank == 0 and world == 1 and args.numerics == "fast" and not args.no_parity_mode:

@@ -201,6 +201,27 @@ int ufm_conv2d_nhwc_bf16x3(const uint16_t* in, int B, int H, int W, int Cin, con
                                          the arithmetic bf16 autocast gives the reference's UNet (ufm.py:915-917) */,
                            void* stream);
 
+/* =====================================================================================
+ * Numerics mode "precise": the transformer trunk on the split format (fp32-class accuracy at bf16 MFMA rates / 3).
+ * Replaces the same nn.Linear / SDPA call sites as ufm_gemm_bf16 / ufm_attention_bf16 ([U] Attention.qkv/proj,
+ * Mlp.fc1/fc2, Attention.forward), evaluated so that the end-to-end flow stays within the north star's 1e-3 px of the
+ * fp32 reference path (what the reference computes on a CPU, models/base.py:272-274 with autocast disabled).
+ *
+ * ufm_gemm_bf16x3: out[M][N] = epilogue(A[M][K] . W[N][K]^T), every product hi*hi + hi*lo + lo*hi, fp32 accumulate.
+ *   A: UFM_BF16X2 [2][M][K] (ufm_layernorm / ufm_attention_bf16x3 / a previous ufm_gemm_bf16x3 write it);
+ *   W: UFM_BF16X2 [2][N][K], pre-split at pack time.   v = acc + bias[n]; v = act(v) (exact erf GELU); v *= gamma[n];
+ *   out_dtype UFM_BF16X2: out = split(v) as [2][M][N];   out_dtype UFM_F32: v += res[m][n] (fp32, may be NULL, may alias
+ *   out: the fp32 residual stream is updated in place), out[m][n] = v.
+ *   Requirements: K % 32 == 0, N % 32 == 0, 16-byte aligned pointers.  zero_page: >= 128 B of zeros (device).
+ * ufm_attention_bf16x3: softmax(scale * q k^T) v per (batch, head), head_dim 64, non-causal; qkv: UFM_BF16X2
+ *   [2][B*N][3*H*64] (the raw output of the qkv Linear), out: UFM_BF16X2 [2][B*N][H*64]; Q.K^T and P.V both as three
+ *   bf16 MFMA passes (P is split into hi/lo in registers), softmax statistics in fp32.
+ * ===================================================================================== */
+int ufm_gemm_bf16x3(const uint16_t* A, const uint16_t* W, int M, int N, int K, const float* bias, int act,
+                    const float* gamma, const float* res, void* out, int out_dtype, const uint16_t* zero_page,
+                    void* stream);
+int ufm_attention_bf16x3(const uint16_t* qkv, uint16_t* out, int B, int N, int H, float scale, void* stream);
+
 /* Bilinear resize, align_corners=True, NHWC fp32 ([U] FeatureFusionBlock x2 upsample,
  * DPTRegressionProcessor interpolate-to-target).  src = dst*(in-1)/(out-1).  crop_h/crop_w > 0:
  * only the top-left crop_h x crop_w of the (Ho, Wo) result is computed and stored (densely) --

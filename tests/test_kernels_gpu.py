@@ -623,6 +623,83 @@ def test_conv2d_bf16x3(hip, B, H, W, Cin, Cout, k, stride, pad, relu_in, act, nr
     assert err <= 4e-5 * max(1.0, ref.abs().max().item()), err
 
 
+# ---- numerics "precise": the transformer's Linear layers and attention on the split format ----
+@pytest.mark.parametrize(
+    "M,N,K,act,use_gamma,use_res,split_out",
+    [
+        (300, 256, 128, 0, False, False, True),
+        (300, 64, 96, 1, True, False, True),            # GELU (exact erf), 128x64 tiles
+        (257, 128, 64, 0, True, True, False),           # LayerScale + fp32 residual in place
+        (2 * 1370, 3072, 1024, 0, True, False, True),   # QKV shape: 8-phase 256x256 tiles + remainder
+        (2 * 1370, 1024, 4096, 0, True, True, False),   # fc2 shape
+        (8 * 1369 + 5, 768, 768, 0, False, True, False),
+    ],
+)
+def test_gemm_bf16x3(hip, M, N, K, act, use_gamma, use_res, split_out):
+    A = rnd(M, K, seed=1)
+    W = rnd(N, K, seed=2, scale=K**-0.5)
+    bias = rnd(N, seed=3, scale=0.1)
+    gamma = 1 + rnd(N, seed=4, scale=0.1) if use_gamma else None
+    res = rnd(M, N, seed=5) if use_res else None
+    As, Ws = split(A), split(W)
+    ref = unsplit(As).double() @ unsplit(Ws).double().T + bias.double()  # the kernel sees the split operands
+    if act == 1:
+        ref = F.gelu(ref)
+    if gamma is not None:
+        ref = ref * gamma.double()
+    if res is not None:
+        ref = ref + res.double()
+    zero = torch.zeros(256, device=DEV)
+    if split_out:
+        out = torch.full((2, M, N), 7.0, device=DEV, dtype=torch.bfloat16)
+        hip.gemm_x3(As.to(DEV), Ws.to(DEV), M, N, K, out, zero, bias=bias.to(DEV), act=act, gamma=gamma.to(DEV) if gamma is not None else None)
+        got = unsplit(out.cpu()).double()
+    else:
+        out = res.to(DEV).clone() if res is not None else torch.full((M, N), 7.0, device=DEV)
+        hip.gemm_x3(As.to(DEV), Ws.to(DEV), M, N, K, out, zero, bias=bias.to(DEV), act=act, gamma=gamma.to(DEV) if gamma is not None else None,
+                    res=out if res is not None else None)
+        got = out.cpu().double()
+    err = (got - ref).abs().max().item()
+    # dropped lo*lo terms 2^-16 per product (random signs), fp32 accumulation over K, split store 2^-17
+    assert err <= 4e-5 * max(1.0, ref.abs().max().item()), err
+
+
+def test_gemm_bf16x3_rejects_bad_arguments(hip):
+    z = torch.zeros(256, device=DEV)
+    a, w = torch.zeros(2, 64, 48, device=DEV, dtype=torch.bfloat16), torch.zeros(2, 64, 48, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="multiple of 32"):
+        hip.gemm_x3(a, w, 64, 64, 48, torch.zeros(2, 64, 64, device=DEV, dtype=torch.bfloat16), z)
+    a, w = torch.zeros(2, 64, 64, device=DEV, dtype=torch.bfloat16), torch.zeros(2, 64, 64, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="fp32 output"):
+        hip.gemm_x3(a, w, 64, 64, 64, torch.zeros(2, 64, 64, device=DEV, dtype=torch.bfloat16), z, res=torch.zeros(64, 64, device=DEV))
+
+
+@pytest.mark.parametrize("B,N,H", [(1, 17, 1), (2, 100, 2), (2, 1370, 2), (1, 2738, 3), (1, 64, 1), (1, 129, 1)])
+def test_attention_bf16x3(hip, B, N, H):
+    qkv = rnd(B * N, 3 * H * 64, seed=N, scale=1.5)
+    qs = split(qkv)
+    ref = attn_ref(unsplit(qs), B, N, H, 0.125)
+    out = torch.zeros(2, B * N, H * 64, device=DEV, dtype=torch.bfloat16)
+    hip.attention_x3(qs.to(DEV), out, B, N, H, 0.125)
+    err = (unsplit(out.cpu()).double() - ref).abs().max().item()
+    assert err <= 3e-5, err  # |O| <~ 1; scores carry ~2^-17 * sum|q||k|, P and O are split to 2^-17
+
+
+def test_attention_bf16x3_spike_moves_the_running_maximum(hip):
+    """One key per 64-key tile with a growing score: every tile moves the running maximum (the rescale branch), then a long
+    flat stretch where it never moves (the skipped-rescale branch); checked against the fp64 statement on every row."""
+    B, N, H = 1, 64 * 9 + 7, 1
+    qkv = rnd(B * N, 3 * 64, seed=11, scale=0.5)
+    for t in range(5):
+        qkv[t * 64 + 13, 64:128] = qkv[3, 0:64] * (4.0 + 6.0 * t)  # key t*64+13 aligned with query 3 (and friends)
+    qs = split(qkv)
+    ref = attn_ref(unsplit(qs), B, N, H, 0.125)
+    out = torch.zeros(2, B * N, H * 64, device=DEV, dtype=torch.bfloat16)
+    hip.attention_x3(qs.to(DEV), out, B, N, H, 0.125)
+    err = (unsplit(out.cpu()).double() - ref).abs().max().item()
+    assert err <= 3e-5, err
+
+
 @pytest.mark.parametrize(
     "B,H,W,Cin,Cout,k,stride,pad,relu_in,act",
     [

@@ -64,6 +64,9 @@ def test_tiny_parity_mode_identity_resolution(env, refine):
     p = prod.predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
     df, dm, mx = compare(o, p)
     assert df <= 1e-3 and dm <= 1e-3, (df, dm, mx)
+    pp = prod.set_numerics("precise").predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
+    dfp, dmp, _ = compare(o, pp)
+    assert dfp <= 1e-3 and dmp <= 1e-3, ("precise", dfp, dmp, mx)
     assert p.covisibility.logits is None and p.covisibility.mask.shape == (2, 56, 56)
     if refine:
         assert p.classification_refinement is None  # un-mapped result carries flow + covisibility only (base.py:276-334)
@@ -186,6 +189,12 @@ def test_ufm_base_full_size_parity(env):
     dfx, dmx, _ = compare(o, px)
     print(f"UFM-Base 518 fp32 trunk + bf16x3 heads: flow max-abs {dfx:.3g} px, mask {dmx:.3g}")
     assert dfx <= 1e-3 and dmx <= 1e-3, (dfx, dmx, mx)
+    # "precise": bf16x3 split precision for EVERY contraction (trunk GEMMs, attention, heads) -- the 1e-3 px gate at
+    # bf16-matrix-core rates
+    pp = prod.set_numerics("precise").predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
+    dfp, dmp, _ = compare(o, pp)
+    print(f"UFM-Base 518 precise (bf16x3 everywhere): flow max-abs {dfp:.3g} px, mask {dmp:.3g}")
+    assert dfp <= 1e-3 and dmp <= 1e-3, (dfp, dmp, mx)
     pf = prod.set_numerics("fast").predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
     df2, dm2, _ = compare(o, pf)
     mean_abs = (o.flow.flow_output - pf.flow.flow_output.cpu()).abs().mean().item()
@@ -225,6 +234,10 @@ def test_config4_ufm_refine_full_size_parity(env):
     dfx, dmx, _ = compare(o, px)
     print(f"UFM-Refine 518 fp32 trunk + bf16x3 heads and classification MLP: flow max-abs {dfx:.3g} px, mask {dmx:.3g}")
     assert dfx <= 1e-3 and dmx <= 1e-3, (dfx, dmx, mx)
+    pp = prod.set_numerics("precise").predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
+    dfp, dmp, _ = compare(o, pp)
+    print(f"UFM-Refine 518 precise (bf16x3 everywhere): flow max-abs {dfp:.3g} px, mask {dmp:.3g}")
+    assert dfp <= 1e-3 and dmp <= 1e-3, (dfp, dmp, mx)
     pf = prod.set_numerics("fast").predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
     dff, dmf, _ = compare(o, pf)
     print(f"UFM-Refine 518 fast mode: flow max-abs {dff:.3g} px (range {mx:.3g}), mask {dmf:.3g}")
@@ -282,6 +295,10 @@ def test_config5_1036_parity_vs_oracle(env):
     df, dm, mx = compare(o, p)
     print(f"UFM-Base 1036 parity mode: flow max-abs {df:.3g} px (range {mx:.3g}), mask {dm:.3g}")
     assert df <= 1e-3 and dm <= 1e-3, (df, dm, mx)
+    pp = prod.set_numerics("precise").predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
+    dfp, dmp, _ = compare(o, pp)
+    print(f"UFM-Base 1036 precise (bf16x3 everywhere): flow max-abs {dfp:.3g} px, mask {dmp:.3g}")
+    assert dfp <= 1e-3 and dmp <= 1e-3, (dfp, dmp, mx)
     pf = prod.set_numerics("fast").predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
     df2, dm2, _ = compare(o, pf)
     print(f"UFM-Base 1036 fast mode: flow max-abs {df2:.3g} px (range {mx:.3g}), mask {dm2:.3g}")

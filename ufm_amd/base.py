@@ -82,10 +82,12 @@ class UniFlowMatchModelsBase(torch.nn.Module):
     # --- engine plumbing -------------------------------------------------------------------
     def set_numerics(self, numerics: str) -> "UniFlowMatchModelsBase":
         """"fast": bf16 MFMA trunk (the reference's GPU autocast policy) + bf16x3 split-precision heads;
+        "precise": bf16x3 split precision for the trunk too (fp32-class accuracy on the bf16 matrix cores: the mode that
+        meets the 1e-3 px tolerance without the exact-fp32 MFMA's 1/16 rate);
         "parity": fp32 MFMA everywhere; "parity_x3heads": fp32 MFMA trunk + the bf16x3 heads of "fast"
         (isolates the one choice of "fast" that is narrower than the reference's fp32 head island, ufm.py:635)."""
-        if numerics not in ("fast", "parity", "parity_x3heads"):
-            raise ValueError("numerics must be 'fast', 'parity' or 'parity_x3heads'")
+        if numerics not in ("fast", "precise", "parity", "parity_x3heads"):
+            raise ValueError("numerics must be 'fast', 'precise', 'parity' or 'parity_x3heads'")
         if numerics != self.numerics:
             self.numerics, self._engine = numerics, None
         return self

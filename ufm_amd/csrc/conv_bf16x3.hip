@@ -195,6 +195,71 @@ extern "C" int ufm_debug_set_conv_variant(int v) {
     return UFM_OK;
 }
 
+// Kernel choice for one problem (shared by the convolution and the Linear entry points).
+static void launch_conv_x3(const ConvX3Args& p, int passes, hipStream_t stream) {
+    const int Cout = p.Cout, KH = p.KH, KW = p.KW, Cin = p.Cin;
+    const long long M = p.M;
+    // Kernel choice.  Cout % 256 == 0 and a grid that fills the chip: the 256x256 8-phase kernel on the leading pixels
+    // that make whole rounds of 256 CUs, the 128-row kernel on the rest (g_conv_variant: 0 auto, 1 = 128-row kernels
+    // only, 2 = 8-phase on everything it accepts -- tests/tools).
+    auto launch128 = [&](const ConvX3Args& q) {
+        const long long Mq = q.M - q.m_begin;
+        const int ntm = (int)((Mq + 127) / 128);
+        const long long blocks128 = (long long)ntm * (Cout % 128 == 0 ? Cout / 128 : Cout % 64 == 0 ? Cout / 64 : Cout / 32);
+        // small grid: 64x64 tiles, several co-resident blocks per CU.  Threshold from an end-to-end sweep (400 / 200 / 100:
+        // 189.6 / 196.6 / 197.2 pairs/s with two micro-batches): at 128..400 blocks the 128-row tiles win
+        if (passes == 1) {  // plain bf16: the two-stage kernels only
+            if (Cout % 64 == 0 && blocks128 < 128)
+                hipLaunchKernelGGL((conv_x3_kernel<64, 64, 2, 1>), dim3((unsigned)(((Mq + 63) / 64) * (Cout / 64))), dim3(256), 0, stream, q);
+            else if (Cout % 128 == 0)
+                hipLaunchKernelGGL((conv_x3_kernel<128, 128, 2, 1>), dim3(ntm * (Cout / 128)), dim3(256), 0, stream, q);
+            else if (Cout % 64 == 0)
+                hipLaunchKernelGGL((conv_x3_kernel<128, 64, 2, 1>), dim3(ntm * (Cout / 64)), dim3(256), 0, stream, q);
+            else
+                hipLaunchKernelGGL((conv_x3_kernel<128, 32, 2, 1>), dim3(ntm * (Cout / 32)), dim3(256), 0, stream, q);
+            return;
+        }
+        if (Cout % 64 == 0 && blocks128 < 128) {
+            const unsigned grid = (unsigned)(((Mq + 63) / 64) * (Cout / 64));
+            // measured per layer (tools/conv_breakdown.py): the deep ring pays on long K loops only (19^2 768->256: 138 -> 102 us;
+            // short loops lose 2-3 us to its prologue), and not at all on the 128x128 tile (37^2 RCU: 68 -> 83 us)
+            if (grid <= 512 && KH * KW * (Cin / 32) >= 64 && g_conv_variant != 3)
+                hipLaunchKernelGGL((conv_x3_kernel<64, 64, 4>), dim3(grid), dim3(256), 0, stream, q);
+            else
+                hipLaunchKernelGGL((conv_x3_kernel<64, 64, 2>), dim3(grid), dim3(256), 0, stream, q);
+        } else if (Cout % 128 == 0) {
+            hipLaunchKernelGGL((conv_x3_kernel<128, 128, 2>), dim3(ntm * (Cout / 128)), dim3(256), 0, stream, q);
+        } else if (Cout % 64 == 0) {
+            hipLaunchKernelGGL((conv_x3_kernel<128, 64, 2>), dim3(ntm * (Cout / 64)), dim3(256), 0, stream, q);
+        } else {
+            hipLaunchKernelGGL((conv_x3_kernel<128, 32, 2>), dim3(ntm * (Cout / 32)), dim3(256), 0, stream, q);
+        }
+    };
+    // 8-phase tile: 256 px x 256 cout (Cout % 256 == 0)
+    const int tile_n = 256, tile_m = 256;
+    const bool ok8 = Cout % 256 == 0 && KH * KW * (Cin / 32) >= 2 && p.in_plane < (1ll << 31) && p.w_plane < (1ll << 31);
+    const long long t8 = ((M + tile_m - 1) / tile_m) * (Cout / tile_n);
+    if (passes == 1) {
+        launch128(p);
+    } else if (ok8 && g_conv_variant == 2) {
+        ufm_launch_conv_x3_8ph(p, stream);
+    } else if (ok8 && g_conv_variant == 0 && t8 >= 256) {  // (variants 1 and 3 never take this branch)
+        const long long full = t8 / 256;                                // whole rounds of the 8-phase kernel
+        const long long m_main = full * 256 / (Cout / tile_n) * tile_m;  // leading pixels whose tiles fit in them
+        if (m_main >= M || full == 0) {
+            ufm_launch_conv_x3_8ph(p, stream);
+        } else {
+            ConvX3Args lead = p, rest = p;
+            lead.M = (int)m_main;
+            rest.m_begin = (int)m_main;
+            ufm_launch_conv_x3_8ph(lead, stream);
+            launch128(rest);
+        }
+    } else {
+        launch128(p);
+    }
+}
+
 extern "C" int ufm_conv2d_nhwc_bf16x3(const uint16_t* in, int B, int H, int W, int Cin, const uint16_t* weight, int Cout,
                                       int KH, int KW, int stride, int pad, int relu_in, const float* bias, int act,
                                       const uint16_t* res1, const uint16_t* res2, int shuffle, uint16_t* out,
@@ -221,65 +286,32 @@ extern "C" int ufm_conv2d_nhwc_bf16x3(const uint16_t* in, int B, int H, int W, i
     ConvX3Args p{in, weight, bias, res1, res2, zero_page, out, out_relu,
                  (long long)B * H * W * Cin, (long long)Cout * KH * KW * Cin, Mout * Co,
                  B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, (int)M, relu_in, act, shuffle, Co, 0};
-    // Kernel choice.  Cout % 256 == 0 and a grid that fills the chip: the 256x256 8-phase kernel on the leading pixels
-    // that make whole rounds of 256 CUs, the 128-row kernel on the rest (g_conv_variant: 0 auto, 1 = 128-row kernels
-    // only, 2 = 8-phase on everything it accepts -- tests/tools).
-    auto launch128 = [&](const ConvX3Args& q) {
-        const long long Mq = q.M - q.m_begin;
-        const int ntm = (int)((Mq + 127) / 128);
-        const long long blocks128 = (long long)ntm * (Cout % 128 == 0 ? Cout / 128 : Cout % 64 == 0 ? Cout / 64 : Cout / 32);
-        // small grid: 64x64 tiles, several co-resident blocks per CU.  Threshold from an end-to-end sweep (400 / 200 / 100:
-        // 189.6 / 196.6 / 197.2 pairs/s with two micro-batches): at 128..400 blocks the 128-row tiles win
-        if (passes == 1) {  // plain bf16: the two-stage kernels only
-            if (Cout % 64 == 0 && blocks128 < 128)
-                hipLaunchKernelGGL((conv_x3_kernel<64, 64, 2, 1>), dim3((unsigned)(((Mq + 63) / 64) * (Cout / 64))), dim3(256), 0, (hipStream_t)stream, q);
-            else if (Cout % 128 == 0)
-                hipLaunchKernelGGL((conv_x3_kernel<128, 128, 2, 1>), dim3(ntm * (Cout / 128)), dim3(256), 0, (hipStream_t)stream, q);
-            else if (Cout % 64 == 0)
-                hipLaunchKernelGGL((conv_x3_kernel<128, 64, 2, 1>), dim3(ntm * (Cout / 64)), dim3(256), 0, (hipStream_t)stream, q);
-            else
-                hipLaunchKernelGGL((conv_x3_kernel<128, 32, 2, 1>), dim3(ntm * (Cout / 32)), dim3(256), 0, (hipStream_t)stream, q);
-            return;
-        }
-        if (Cout % 64 == 0 && blocks128 < 128) {
-            const unsigned grid = (unsigned)(((Mq + 63) / 64) * (Cout / 64));
-            // measured per layer (tools/conv_breakdown.py): the deep ring pays on long K loops only (19^2 768->256: 138 -> 102 us;
-            // short loops lose 2-3 us to its prologue), and not at all on the 128x128 tile (37^2 RCU: 68 -> 83 us)
-            if (grid <= 512 && KH * KW * (Cin / 32) >= 64 && g_conv_variant != 3)
-                hipLaunchKernelGGL((conv_x3_kernel<64, 64, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, q);
-            else
-                hipLaunchKernelGGL((conv_x3_kernel<64, 64, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, q);
-        } else if (Cout % 128 == 0) {
-            hipLaunchKernelGGL((conv_x3_kernel<128, 128, 2>), dim3(ntm * (Cout / 128)), dim3(256), 0, (hipStream_t)stream, q);
-        } else if (Cout % 64 == 0) {
-            hipLaunchKernelGGL((conv_x3_kernel<128, 64, 2>), dim3(ntm * (Cout / 64)), dim3(256), 0, (hipStream_t)stream, q);
-        } else {
-            hipLaunchKernelGGL((conv_x3_kernel<128, 32, 2>), dim3(ntm * (Cout / 32)), dim3(256), 0, (hipStream_t)stream, q);
-        }
-    };
-    // 8-phase tile: 256 px x 256 cout (Cout % 256 == 0)
-    const int tile_n = 256, tile_m = 256;
-    const bool ok8 = Cout % 256 == 0 && KH * KW * (Cin / 32) >= 2 && p.in_plane < (1ll << 31) && p.w_plane < (1ll << 31);
-    const long long t8 = ((M + tile_m - 1) / tile_m) * (Cout / tile_n);
-    if (passes == 1) {
-        launch128(p);
-    } else if (ok8 && g_conv_variant == 2) {
-        ufm_launch_conv_x3_8ph(p, (hipStream_t)stream);
-    } else if (ok8 && g_conv_variant == 0 && t8 >= 256) {  // (variants 1 and 3 never take this branch)
-        const long long full = t8 / 256;                                // whole rounds of the 8-phase kernel
-        const long long m_main = full * 256 / (Cout / tile_n) * tile_m;  // leading pixels whose tiles fit in them
-        if (m_main >= M || full == 0) {
-            ufm_launch_conv_x3_8ph(p, (hipStream_t)stream);
-        } else {
-            ConvX3Args lead = p, rest = p;
-            lead.M = (int)m_main;
-            rest.m_begin = (int)m_main;
-            ufm_launch_conv_x3_8ph(lead, (hipStream_t)stream);
-            launch128(rest);
-        }
-    } else {
-        launch128(p);
-    }
+    launch_conv_x3(p, passes, (hipStream_t)stream);
     UFM_CHECK_LAUNCH("ufm_conv2d_nhwc_bf16x3");
+    return UFM_OK;
+}
+
+// Linear layer on the split format: out[M][N] = epilogue(A[M][K] . W[N][K]^T), every product hi*hi + hi*lo + lo*hi.
+// The 1x1 convolution over M "pixels" it is, with the transformer's Linear epilogue (bias, activation, per-column
+// scale, fp32 residual in place) -- numerics mode "precise".
+extern "C" int ufm_gemm_bf16x3(const uint16_t* A, const uint16_t* W, int M, int N, int K, const float* bias, int act,
+                               const float* gamma, const float* res, void* out, int out_dtype, const uint16_t* zero_page,
+                               void* stream) {
+    UFM_REQUIRE(A && W && out && zero_page, "ufm_gemm_bf16x3: null pointer");
+    UFM_REQUIRE(M > 0 && N > 0 && K > 0, "ufm_gemm_bf16x3: bad shape M=%d N=%d K=%d", M, N, K);
+    UFM_REQUIRE(K % BK == 0, "ufm_gemm_bf16x3: K=%d must be a multiple of %d", K, BK);
+    UFM_REQUIRE(N % 32 == 0, "ufm_gemm_bf16x3: N=%d must be a multiple of 32", N);
+    UFM_REQUIRE(out_dtype == UFM_F32 || out_dtype == UFM_BF16X2, "ufm_gemm_bf16x3: out_dtype must be UFM_F32 or UFM_BF16X2");
+    UFM_REQUIRE(out_dtype == UFM_F32 || !res, "ufm_gemm_bf16x3: the fp32 residual needs an fp32 output");
+    UFM_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)out % 16) == 0, "ufm_gemm_bf16x3: misaligned pointer");
+    UFM_REQUIRE((long long)M * K < (1ll << 31) && (long long)N * K < (1ll << 31) && (long long)M * N < (1ll << 31), "ufm_gemm_bf16x3: problem too large");
+    ConvX3Args p{A, W, bias, nullptr, nullptr, zero_page, out_dtype == UFM_BF16X2 ? (uint16_t*)out : nullptr, nullptr,
+                 (long long)M * K, (long long)N * K, (long long)M * N,
+                 1, 1, M, K, N, 1, 1, 1, 0, 1, M, M, 0, act, 0, N, 0};
+    p.gamma = gamma;
+    p.res_f32 = res;
+    p.out_f32 = out_dtype == UFM_F32 ? (float*)out : nullptr;
+    launch_conv_x3(p, 3, (hipStream_t)stream);
+    UFM_CHECK_LAUNCH("ufm_gemm_bf16x3");
     return UFM_OK;
 }

@@ -15,6 +15,10 @@ struct ConvX3Args {
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, M;
     int relu_in, act, shuffle, Co;
     int m_begin;  // the launch covers output pixels [m_begin, M) (hybrid 8-phase + 128-row split of one conv)
+    // Linear-layer epilogue of ufm_gemm_bf16x3 (numerics "precise": the transformer trunk on the split format)
+    const float* gamma;    // per-output-channel scale after the activation (LayerScale / Q pre-scale) or null
+    const float* res_f32;  // fp32 residual [M][Cout] added after gamma (may alias out_f32) or null
+    float* out_f32;        // non-null: the result is stored as fp32 [M][Cout] instead of the split planes
 };
 
 static __device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
@@ -88,6 +92,12 @@ static __device__ __forceinline__ void conv_x3_epilogue(const ConvX3Args& p, f32
             for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act);
         }
         const size_t o = (size_t)pix * p.Cout + cb;
+        if (p.gamma) v *= *(const f32x4*)(p.gamma + cb);
+        if (p.out_f32) {  // fp32 residual stream, read-modify-write in place
+            if (p.res_f32) v += *(const f32x4*)(p.res_f32 + o);
+            *(f32x4*)(p.out_f32 + o) = v;
+            continue;
+        }
         if (p.res1) v += split_load4(p.res1 + o, p.out_plane);
         if (p.res2) v += split_load4(p.res2 + o, p.out_plane);
         split_store4(p.out + o, p.out_plane, v);

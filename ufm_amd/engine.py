@@ -17,8 +17,11 @@ Data layout in HBM
     pick view 1) -- the reference's ``.float().contiguous()`` copies (ufm.py:602-630) do not exist.
 
 Numerics modes
-  "fast"   bf16 MFMA operands, fp32 accumulate, fp32 residual / LayerNorm / softmax statistics.
-  "parity" exact-fp32 MFMA for every contraction; tracks the fp32 CPU oracle to <= 1e-3 px.
+  "fast"    bf16 MFMA operands, fp32 accumulate, fp32 residual / LayerNorm / softmax statistics.
+  "precise" every contraction of the trunk AND the heads in bf16x3 split precision (hi*hi + hi*lo + lo*hi on the bf16
+            matrix cores, activations carried as (hi, lo) bf16 planes, fp32 residual stream / LayerNorm / softmax
+            statistics): tracks the fp32 CPU oracle to <= 1e-3 px at a third of the bf16 MFMA rate.
+  "parity"  exact-fp32 MFMA for every contraction; tracks the fp32 CPU oracle to <= 1e-3 px.
 """
 
 from __future__ import annotations
@@ -40,12 +43,22 @@ def _f32(t: torch.Tensor, dev) -> torch.Tensor:
     return t.detach().to(device=dev, dtype=torch.float32).contiguous()
 
 
+def _split_bf16(w: torch.Tensor) -> torch.Tensor:
+    """fp32 -> UFM_BF16X2: stack(hi = bf16(w), lo = bf16(w - hi))."""
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    return torch.stack([hi, lo], dim=0).contiguous()
+
+
 class _Lin:
     """Packed nn.Linear: weight in the mode's operand dtype, bias fp32."""
 
-    def __init__(self, lin: nn.Linear, dev, wdt):
+    def __init__(self, lin: nn.Linear, dev, wdt, split: bool = False):
         self.n, self.k = lin.weight.shape
-        self.w = lin.weight.detach().to(device=dev, dtype=wdt).contiguous()
+        if split:  # UFM_BF16X2 (2, N, K) for ufm_gemm_bf16x3
+            self.w = _split_bf16(lin.weight.detach().to(device=dev, dtype=torch.float32))
+        else:
+            self.w = lin.weight.detach().to(device=dev, dtype=wdt).contiguous()
         self.b = _f32(lin.bias, dev) if lin.bias is not None else None
 
 
@@ -53,26 +66,19 @@ LOG2E = 1.4426950408889634
 
 
 class _Blk:
-    def __init__(self, blk, dev, wdt):
+    def __init__(self, blk, dev, wdt, split: bool = False):
         self.n1w, self.n1b = _f32(blk.norm1.weight, dev), _f32(blk.norm1.bias, dev)
         self.n2w, self.n2b = _f32(blk.norm2.weight, dev), _f32(blk.norm2.bias, dev)
-        self.qkv, self.proj = _Lin(blk.attn.qkv, dev, wdt), _Lin(blk.attn.proj, dev, wdt)
-        self.fc1, self.fc2 = _Lin(blk.mlp.fc1, dev, wdt), _Lin(blk.mlp.fc2, dev, wdt)
+        self.qkv, self.proj = _Lin(blk.attn.qkv, dev, wdt, split), _Lin(blk.attn.proj, dev, wdt, split)
+        self.fc1, self.fc2 = _Lin(blk.mlp.fc1, dev, wdt, split), _Lin(blk.mlp.fc2, dev, wdt, split)
         self.ls1 = _f32(blk.ls1.gamma, dev) if hasattr(blk.ls1, "gamma") else None
         self.ls2 = _f32(blk.ls2.gamma, dev) if hasattr(blk.ls2, "gamma") else None
         # fast mode: the QKV epilogue scales the Q columns by softmax_scale*log2(e) BEFORE the bf16 rounding,
         # so the attention kernel works in the log2 domain with no per-score multiply and no extra rounding
         d = self.qkv.n // 3
         self.qscale = None
-        if wdt == torch.bfloat16:
+        if wdt == torch.bfloat16 and not split:
             self.qscale = torch.cat([torch.full((d,), 0.125 * LOG2E), torch.ones(2 * d)]).to(device=dev, dtype=torch.float32)
-
-
-def _split_bf16(w: torch.Tensor) -> torch.Tensor:
-    """fp32 -> UFM_BF16X2: stack(hi = bf16(w), lo = bf16(w - hi))."""
-    hi = w.to(torch.bfloat16)
-    lo = (w - hi.float()).to(torch.bfloat16)
-    return torch.stack([hi, lo], dim=0).contiguous()
 
 
 class _Conv:
@@ -145,12 +151,13 @@ class _Head:
 
 class Engine:
     def __init__(self, model: nn.Module, numerics: str = "fast"):
-        if numerics not in ("fast", "parity", "parity_x3heads"):
-            raise ValueError("numerics must be 'fast', 'parity' or 'parity_x3heads'")
+        if numerics not in ("fast", "precise", "parity", "parity_x3heads"):
+            raise ValueError("numerics must be 'fast', 'precise', 'parity' or 'parity_x3heads'")
         hip.lib()  # fail loudly right here if the extension is missing
         self.model = model
         self.numerics = numerics
         self.adt = torch.bfloat16 if numerics == "fast" else torch.float32  # GEMM/attention operand dtype
+        self.trunk_x3 = numerics == "precise"  # transformer blocks on the split format (ufm_gemm_bf16x3 / ufm_attention_bf16x3)
         self.dev: Optional[torch.device] = None
         self._bufs: Dict[str, torch.Tensor] = {}
         self._tables: Dict[Any, Any] = {}
@@ -191,17 +198,17 @@ class Engine:
         w[:, : pe_w.shape[1]] = pe_w.cpu()
         self.pe_w = w.to(device=dev, dtype=wdt).contiguous()
         self.pe_b = _f32(enc.patch_embed.proj.bias, dev)
-        self.enc_blocks = [_Blk(b, dev, wdt) for b in enc.blocks]
+        self.enc_blocks = [_Blk(b, dev, wdt, self.trunk_x3) for b in enc.blocks]
         self.enc_norm = (_f32(enc.norm.weight, dev), _f32(enc.norm.bias, dev))
         info = m.info_sharing
         self.Di, self.info_heads, self.info_indices = info.dim, info.num_heads, list(info.indices)
         self.info_proj = _Lin(info.proj_embed, dev, wdt) if isinstance(info.proj_embed, nn.Linear) else None
-        self.info_blocks = [_Blk(b, dev, wdt) for b in info.self_attention_blocks]
+        self.info_blocks = [_Blk(b, dev, wdt, self.trunk_x3) for b in info.self_attention_blocks]
         self.info_norm = (_f32(info.norm.weight, dev), _f32(info.norm.bias, dev))
         if info.max_num_views < 2:
             raise ValueError("info sharing needs max_num_views >= 2")
         # DPT heads: exact-fp32 MFMA in "parity"; bf16x3 split precision (UFM_BF16X2 activations) in "fast"
-        self.head_split = self.numerics in ("fast", "parity_x3heads")
+        self.head_split = self.numerics in ("fast", "precise", "parity_x3heads")
         self.heads = {"head1": _Head(m.head1, dev, self.head_split)}
         if hasattr(m, "uncertainty_head"):
             self.heads["uncertainty_head"] = _Head(m.uncertainty_head, dev, self.head_split)
@@ -316,8 +323,12 @@ class Engine:
         return self._tables[key]
 
     def linear(self, x, lin: _Lin, M: int, out, *, act=hip.ACT_NONE, gamma=None, res=None, res_row_mod=0, out_row_group=0, lda=None):
-        """out = epilogue(x @ W^T): bf16 MFMA GEMM in 'fast', exact-fp32 MFMA (conv kernel as dense GEMM) in 'parity'."""
-        if lin.w.dtype == torch.bfloat16:
+        """out = epilogue(x @ W^T): bf16 MFMA GEMM in 'fast', the bf16x3 split form in 'precise', exact-fp32 MFMA (conv
+        kernel as dense GEMM) in 'parity'."""
+        if lin.w.dim() == 3:  # UFM_BF16X2 weights: x is a (2, M, K) split buffer, out split or the fp32 residual stream
+            assert res_row_mod == 0 and out_row_group == 0 and lda is None
+            hip.gemm_x3(x, lin.w, M, lin.n, lin.k, out, self.zero, bias=lin.b, act=act, gamma=gamma, res=res)
+        elif lin.w.dtype == torch.bfloat16:
             hip.gemm_bf16(x, lin.w, M, lin.n, lin.k, out, bias=lin.b, act=act, gamma=gamma, res=res, res_row_mod=res_row_mod, out_row_group=out_row_group, lda=lda)
         else:
             assert res_row_mod == 0 and out_row_group == 0 and out.dtype == torch.float32
@@ -346,16 +357,18 @@ class Engine:
     # ------------------------------------------------------------------ transformer
     def _blocks(self, blocks: List[_Blk], x, Bseq: int, N: int, D: int, heads: int, on_block):
         M = Bseq * N
-        xn = self.buf("xn", (M, D), self.adt)
-        qkv = self.buf("qkv", (M, 3 * D), self.adt)
-        ao = self.buf("ao", (M, D), self.adt)
-        hid = self.buf("hid", (M, blocks[0].fc1.n), self.adt)
+        x3 = self.trunk_x3
+        tb = (lambda name, cols: self.buf(name + "_x2", (2, M, cols), torch.bfloat16)) if x3 else (lambda name, cols: self.buf(name, (M, cols), self.adt))
+        xn, qkv, ao, hid = tb("xn", D), tb("qkv", 3 * D), tb("ao", D), tb("hid", blocks[0].fc1.n)
         for i, w in enumerate(blocks):
-            hip.layernorm(x, D, None, M, D, w.n1w, w.n1b, 1e-6, xn)
+            hip.layernorm(x, D, None, M, D, w.n1w, w.n1b, 1e-6, xn, split=x3)
             self.linear(xn, w.qkv, M, qkv, gamma=w.qscale)
-            hip.attention(qkv, ao, Bseq, N, heads, 0.0 if w.qscale is not None else 0.125)
+            if x3:
+                hip.attention_x3(qkv, ao, Bseq, N, heads, 0.125)
+            else:
+                hip.attention(qkv, ao, Bseq, N, heads, 0.0 if w.qscale is not None else 0.125)
             self.linear(ao, w.proj, M, x, gamma=w.ls1, res=x)
-            hip.layernorm(x, D, None, M, D, w.n2w, w.n2b, 1e-6, xn)
+            hip.layernorm(x, D, None, M, D, w.n2w, w.n2b, 1e-6, xn, split=x3)
             self.linear(xn, w.fc1, M, hid, act=hip.ACT_GELU)
             self.linear(hid, w.fc2, M, x, gamma=w.ls2, res=x)
             on_block(i, x)

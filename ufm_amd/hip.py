@@ -46,6 +46,8 @@ SIGNATURES = {
     "ufm_debug_attention_stamps": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "ufm_conv2d_nhwc_f32": [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp],
     "ufm_conv2d_nhwc_bf16x3": [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp],
+    "ufm_gemm_bf16x3": [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp],
+    "ufm_attention_bf16x3": [_vp, _vp, _i, _i, _i, _f, _vp],
     "ufm_upsample_bilinear_nhwc": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp],
     "ufm_head_tail": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _ip, _fp3, _fp3, _vp, _vp, _vp],
     "ufm_adaptor_covariance2d": [_vp, _i, _i, _vp, _vp, _vp, _vp],
@@ -204,6 +206,21 @@ def attention(qkv, out, B, N, H, scale):
     else:
         _t("ufm_attention_f32", 4.0 * B * H * N * N * 64)
         _check(lib().ufm_attention_f32(_p(qkv), _p(out), B, N, H, scale, _stream()), "ufm_attention_f32")
+
+
+def gemm_x3(A, W, M, N, K, out, zero_page, *, bias=None, act=ACT_NONE, gamma=None, res=None):
+    """Linear on the split format (numerics "precise"): A (2, M, K) / W (2, N, K) bf16 planes; out (2, M, N) bf16 planes,
+    or fp32 (M, N) with the optional fp32 residual `res` (may be `out`)."""
+    split_out = out.dtype == torch.bfloat16
+    assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and (split_out or out.dtype == torch.float32)
+    _t("ufm_gemm_bf16x3", 2.0 * M * N * K)
+    _check(lib().ufm_gemm_bf16x3(_p(A), _p(W), M, N, K, _p(bias), act, _p(gamma), _p(res), _p(out), BF16X2 if split_out else F32, _p(zero_page), _stream()), "ufm_gemm_bf16x3")
+
+
+def attention_x3(qkv, out, B, N, H, scale):
+    """Attention on the split format: qkv (2, B*N, 3*H*64), out (2, B*N, H*64) bf16 planes."""
+    _t("ufm_attention_bf16x3", 4.0 * B * H * N * N * 64)
+    _check(lib().ufm_attention_bf16x3(_p(qkv), _p(out), B, N, H, scale, _stream()), "ufm_attention_bf16x3")
 
 
 def conv2d(x, B, H, W, Cin, weight, Cout, KH, KW, stride, pad, out, zero_page, *, relu_in=False, bias=None, act=ACT_NONE, gamma=None, res1=None, res2=None, shuffle=0):
