@@ -125,6 +125,12 @@ def test_checkpoint_loading_is_never_silent(tmp_path):
     ok = ufm_amd.UniFlowMatchConfidence.from_pretrained(variant("extra", lambda s2: s2.update({"encoder.model.mask_token": torch.zeros(1, 128)})))
     for (k1, v1), (k2, v2) in zip(sorted(m.state_dict().items()), sorted(ok.state_dict().items())):
         assert k1 == k2 and torch.equal(v1, v2)
+    # keys of encoder variants this build does not implement are refused by name (a DINOv2-with-registers checkpoint would
+    # otherwise load into the plain encoder and run to wrong outputs); the reference's Lightning path is strict too (ufm.py:203-211)
+    with pytest.raises(RuntimeError, match="register"):
+        ufm_amd.UniFlowMatchConfidence.from_pretrained(variant("registers", lambda s2: s2.update({"encoder.model.register_tokens": torch.zeros(1, 4, 128)})))
+    with pytest.raises(RuntimeError, match="does not have"):
+        ufm_amd.UniFlowMatchConfidence.from_pretrained(variant("rope", lambda s2: s2.update({"info_sharing.rope.cache": torch.zeros(4)})))
     # an unknown extra key is an error too (it usually means a renamed parameter)
     with pytest.raises(RuntimeError, match="does not have"):
         ufm_amd.UniFlowMatchConfidence.from_pretrained(variant("junk", lambda s2: s2.update({"encoder.model.something_new": torch.zeros(1)})))
@@ -161,3 +167,12 @@ def test_uncertainty_head_with_covariance_and_keypoint_confidence_constructs():
     assert [a.required_channels for a in ad] == [1, 3, 1] and m.uncertainty_head[0][1].output_dim == 5
     with pytest.raises(ValueError, match="adaptors need"):
         ufm_amd.UniFlowMatchConfidence(**{**cfg, "uncertainty_head_kwargs": {**cfg["uncertainty_head_kwargs"], "dpt_processor": dict(input_feature_dim=64, output_dim=4)}})
+
+
+def test_confidence_adaptor_rejects_unknown_types():
+    """an unknown confidence_type used to fall through to identity."""
+    from ufm_amd.modules import AdaptorSpec
+
+    assert AdaptorSpec("ConfidenceAdaptor", name="c", confidence_type="sigmoid", vmin=0.0, vmax=1.0).confidence_type == 1
+    with pytest.raises(ValueError, match="confidence_type"):
+        AdaptorSpec("ConfidenceAdaptor", name="c", confidence_type="softplus")

@@ -85,3 +85,61 @@ def test_shard_bounds_properties():
             assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             sizes = [h - l for l, h in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _failing_worker(rank, world, port, n_pairs, fail_rank, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ufm_amd.dist import ShardedPredictor, ShardFailed
+
+    g = torch.Generator().manual_seed(0)
+    src = torch.randint(0, 256, (n_pairs, 6, 5, 3), dtype=torch.uint8, generator=g)
+    tgt = torch.randint(0, 256, (n_pairs, 6, 5, 3), dtype=torch.uint8, generator=g)
+    calls = [0]
+
+    def predict(s, t):
+        calls[0] += 1
+        if rank == fail_rank and calls[0] == 2:  # the second step fails on one rank only
+            raise ValueError("boom")
+        return _fake_predict(s, t)
+
+    sp = ShardedPredictor(predict, depth=2)
+    t0 = sp.submit(src, tgt)
+    t1 = sp.submit(src, tgt)  # fail_rank's predict raises in here; submit must still join the collective
+    f, m = sp.result(t0)      # the healthy step is intact on every rank
+    rf, rm = _fake_predict(src, tgt)
+    ok0 = torch.equal(f, rf) and torch.equal(m, rm)
+    try:
+        sp.result(t1)
+        got = None
+    except ShardFailed as exc:
+        got = (list(exc.ranks), type(exc.__cause__).__name__ if exc.__cause__ is not None else None)
+    t2 = sp.submit(src, tgt)  # the predictor stays usable after a failed step
+    f2, m2 = sp.result(t2)
+    ok2 = torch.equal(f2, rf) and torch.equal(m2, rm)
+    sp.drain()
+    ret[rank] = (ok0, got, ok2)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,fail_rank", [(2, 1), (3, 0)])
+def test_a_failing_rank_poisons_the_gather_instead_of_blocking_the_others(world, fail_rank):
+    """ShardedPredictor.submit: an exception inside predict on ONE rank must not leave the others blocked in the
+    all_gather -- the failing rank joins the collective with its status row poisoned and every rank raises ShardFailed
+    from result() of that step (and only that step)."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, 6, fail_rank, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in range(world):
+        ok0, got, ok2 = ret[r]
+        assert ok0 and ok2, r
+        assert got is not None, f"rank {r} did not see the failure"
+        ranks, cause = got
+        assert ranks == [fail_rank]
+        assert cause == ("ValueError" if r == fail_rank else None)  # the local exception is chained on its own rank

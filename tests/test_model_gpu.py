@@ -327,6 +327,49 @@ def test_config1_shapes_unequal_sizes_multi_resolution(env):
         assert df <= 2e-3 * max(s_hw) / 56 and dm <= 1e-3, (s_hw, t_hw, df, dm, mx)
 
 
+EXAMPLE_PAIRS = ("bike", "building", "cook", "fire_academy", "scene")
+
+
+@pytest.mark.parametrize("name", EXAMPLE_PAIRS)
+def test_config1_real_example_pairs_through_cli_loader_vs_oracle(env, golden_dir, name, tmp_path, monkeypatch):
+    """BASELINE config 1 on its REAL inputs: the reference's five examples/image_pairs (tests/golden/images/, BSD-3 data of
+    the reference repo: 1080-wide, half of them RGBA, bike and cook with source and target of different size) decoded by the
+    `ufm infer` loader (RGBA -> RGB), through predict_correspondences_batched with a multi-resolution tiny model (closest-aspect
+    selection + antialiased resize on the GPU), against the oracle on the same decoded arrays; then the CLI itself on the
+    files.  (UFM-Base weights are not available offline: the model is the tiny random-init one -- plumbing, as config 1 says.)"""
+    from PIL import Image
+
+    ufm_amd, R = env
+    from ufm_amd import cli, viz
+
+    def cfg(mod):
+        c = mod.ufm_tiny_config(resolution_wh=(56, 56))
+        c["inference_resolution"] = [(56, 42), (42, 56), (56, 56), (70, 42)]
+        return c
+
+    oracle, prod = build_pair(env, cfg_fn=cfg)
+    prod.set_numerics("parity")
+    f0, f1 = os.path.join(golden_dir, "images", f"{name}_0.png"), os.path.join(golden_dir, "images", f"{name}_1.png")
+    src, tgt = viz.load_rgb(f0), viz.load_rgb(f1)
+    assert src.dtype == np.uint8 and src.shape[2] == 3 and tgt.shape[2] == 3  # RGBA files arrive as RGB
+    assert src.shape[:2] == Image.open(f0).size[::-1] and src.shape[1] == 1080
+    o = oracle.predict_correspondences_batched(torch.from_numpy(src), torch.from_numpy(tgt))
+    p = prod.predict_correspondences_batched(torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV))
+    assert p.flow.flow_output.shape == (1, 2) + src.shape[:2] and p.covisibility.mask.shape == (1,) + src.shape[:2]
+    df, dm, mx = compare(o, p)
+    # un-mapping multiplies network-resolution flow by ~20x (56 -> 1080 px): scale the 1e-3 gate accordingly
+    assert df <= 2e-3 * 1080 / 56 and dm <= 1e-3, (name, df, dm, mx)
+
+    monkeypatch.setattr(cli, "load_model", lambda args: prod.set_numerics(args.numerics))
+    out = tmp_path / "out"
+    cli.main(["infer", f0, f1, "-o", str(out), "--numerics", "parity"])
+    for art, channels in (("flow_visualization.png", 3), ("covisibility_mask.png", 1), ("warped_source.png", 3)):
+        a = np.asarray(Image.open(out / art))
+        assert a.shape[:2] == src.shape[:2] and (a.ndim == 3) == (channels == 3), (art, a.shape)
+    cov = np.asarray(Image.open(out / "covisibility_mask.png")).astype(np.float32) / 255.0
+    assert np.abs(cov - o.covisibility.mask[0].numpy()).max() <= 1.0 / 255 + 1e-3  # the CLI's mask is the oracle's, quantised
+
+
 def test_from_pretrained_roundtrip_on_device(env, tmp_path):
     """save_pretrained(local dir) -> from_pretrained(local dir): config.json + model.safetensors, no network."""
     ufm_amd, R = env
@@ -482,6 +525,52 @@ def test_hip_graph_replay_is_bitwise_eager(env):
             assert torch.equal(got.flow.flow_output, wf) and torch.equal(got.covisibility.mask, wm), (refine, shape, seed)
         with pytest.raises(ValueError, match="different input signature"):
             gp(torch.zeros(3, 56, 56, 3, dtype=torch.uint8, device=DEV), torch.zeros(3, 56, 56, 3, dtype=torch.uint8, device=DEV))
+
+
+def test_hip_graph_survives_eager_calls_with_other_shapes_and_numerics(env):
+    """the captured graph holds raw pointers into an Engine workspace; an eager call at another batch size or a
+    numerics switch on the same model reallocates / drops the SHARED engine.  GraphedPredictor owns a private Engine, so a
+    replay after such calls is still bitwise the eager result; a parameter update is refused instead of replayed stale."""
+    ufm_amd, _ = env
+    _, prod = build_pair(env)
+    prod.set_numerics("fast")
+    a, b = u8((2, 56, 56, 3), 41).to(DEV), u8((2, 56, 56, 3), 42).to(DEV)
+    want = prod.predict_correspondences_batched(a, b).flow.flow_output.clone()
+    gp = ufm_amd.GraphedPredictor(prod, a, b)
+    assert torch.equal(gp(a, b).flow.flow_output, want)
+    big_a, big_b = u8((5, 56, 56, 3), 43).to(DEV), u8((5, 56, 56, 3), 44).to(DEV)
+    prod.predict_correspondences_batched(big_a, big_b)          # another batch size: the shared workspace is reallocated
+    prod.set_numerics("parity").predict_correspondences_batched(big_a, big_b)  # another engine altogether
+    prod.set_numerics("fast")
+    junk = [torch.full((1 << 20,), float("nan"), device=DEV) for _ in range(8)]  # whatever was freed gets overwritten
+    torch.cuda.synchronize()
+    assert torch.equal(gp(a, b).flow.flow_output, want)
+    assert torch.equal(gp(b, a).flow.flow_output, prod.predict_correspondences_batched(b, a).flow.flow_output)
+    del junk
+    with torch.no_grad():
+        next(prod.parameters()).add_(0.0)  # bumps the parameter's version: the packed weights in the graph are stale now
+    with pytest.raises(RuntimeError, match="parameters changed"):
+        gp(a, b)
+
+
+def test_bench_n_gt_1_branch_rehearsed_on_one_rank_over_rccl():
+    """bench.py's own N > 1 path (ShardedPredictor + RCCL all_gather ring + the gathered-vs-recomputed check) run as a child
+    process with UFM_BENCH_FORCE_DIST=1 (a one-rank group on backend nccl): the JSON line must carry the gather check."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    envv = dict(os.environ, UFM_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        envv.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--no-cpu-baseline", "--no-parity-mode", "--no-precise-mode", "--no-latency", "--no-kernel-timing"],
+                       capture_output=True, text=True, timeout=600, env=envv, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["gather_check"] == {"bitwise_equal_to_local_recompute": True, "pairs_gathered": 2}
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] == "weak"
 
 
 def _cov_conf_config(mod):

@@ -40,7 +40,7 @@ def build_parser() -> argparse.ArgumentParser:
     pair.add_argument("--model", **MODEL_FLAG)
     pair.add_argument("--weights", help="local save_pretrained directory or .ckpt file (default: the reference's Hub id)")
     pair.add_argument("--random-init", action="store_true", help="seeded random weights instead of a checkpoint")
-    pair.add_argument("--numerics", choices=("fast", "parity"), default="fast")
+    pair.add_argument("--numerics", choices=("fast", "precise", "parity"), default="fast")
 
     commands.add_parser("test", help="Test installation")
     return root

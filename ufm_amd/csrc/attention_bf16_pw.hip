@@ -586,11 +586,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_pw_kernel(const uint16_t* __r
 }  // namespace
 
 static int attn_pw_grid(int nunits, int nw) {  // persistent: one workgroup of 4 waves (two of 2 waves) per compute unit
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0, n = 0;
-        ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
-    }
+    const int ncu = ufm_device_cu_count();
     const int slots = ncu * (nw == 4 ? 1 : 2);
     return nunits < slots ? nunits : slots;
 }

@@ -34,6 +34,9 @@ void ufm_set_error(const char* fmt, ...);
         }                                                                     \
     } while (0)
 
+// Compute units of the CURRENT device (cached per device id): sizes persistent grids and the whole-rounds dispatch.
+int ufm_device_cu_count();
+
 // ---- bf16 <-> f32 (RNE; plain casts so NaN stays NaN, MI355X_MICROARCH "Correctness boundaries") ----
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((unsigned)h) << 16); }
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) {

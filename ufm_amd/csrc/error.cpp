@@ -2,6 +2,10 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+
 #include "../../include/ufm_hip.h"
 
 static thread_local char g_err[512] = "";
@@ -16,3 +20,18 @@ void ufm_set_error(const char* fmt, ...) {
 extern "C" int ufm_abi_version(void) { return UFM_ABI_VERSION; }
 extern "C" const char* ufm_last_error(void) { return g_err; }
 extern "C" const char* ufm_built_arch(void) { return "gfx950"; }
+
+// Compute units of the current device, cached per device id (a process may drive several devices; the count sizes the
+// persistent attention grid and the GEMM / conv whole-rounds split, so it must follow the device a launch goes to).
+int ufm_device_cu_count() {
+    constexpr int MAXDEV = 64;
+    static std::atomic<int> cache[MAXDEV];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return 256;
+    int n = cache[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cache[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}

@@ -153,13 +153,7 @@ extern "C" int ufm_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int 
     GemmArgs p{A, W, bias, gamma, res, out, lda, ldw, M, N, K, act, ldres, res_row_mod, ldo, out_row_group, g_gemm_flags, 0};
     if (g_gemm_flags & 16) p.lda = 0;
     if (g_gemm_flags & 32) p.ldw = 0;
-    static int ncu_cached = 0;  // compute units of the current device (whole rounds of the one-block-per-CU 8-phase kernel)
-    if (ncu_cached == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ncu_cached = n;
-        else ncu_cached = 256;
-    }
-    const int NCU = ncu_cached;
+    const int NCU = ufm_device_cu_count();  // whole rounds of the one-block-per-CU 8-phase kernel
     const int ntn = N / 256;
     // variant: 0 auto, 1 = 128x128, 4 = 8-phase on all rows, 5 = hybrid (256-row 8-phase tiles on the leading rows that fill
     //          whole rounds of the chip's CUs, the rest by whichever is cheaper: lower 8-phase tiles or the 128x128 kernel)

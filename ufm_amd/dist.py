@@ -34,12 +34,25 @@ def pack_result(flow: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     return torch.cat([flow, mask.unsqueeze(1)], dim=1).contiguous()
 
 
-def _unpack(gathered: torch.Tensor, n_pairs: int, world: int, max_b: int) -> torch.Tensor:
+def _unpack(gathered: torch.Tensor, n_pairs: int, world: int, max_b: int, stride: int = 0) -> torch.Tensor:
+    """``stride``: rows per rank in ``gathered`` (max_b, or max_b + 1 with ShardedPredictor's status row)."""
+    stride = stride or max_b
     parts = []
     for r in range(world):
         lo, hi = shard_bounds(n_pairs, r, world)
-        parts.append(gathered[r * max_b : r * max_b + (hi - lo)])
+        parts.append(gathered[r * stride : r * stride + (hi - lo)])
     return torch.cat(parts, dim=0)
+
+
+class ShardFailed(RuntimeError):
+    """``predict`` raised on at least one rank of the gather (``.ranks``: which; the local exception is chained on its rank)."""
+
+    def __init__(self, ranks, ticket):
+        super().__init__(f"predict failed on rank(s) {ranks} for ticket {ticket}; the gathered results are not valid")
+        self.ranks, self.ticket = ranks, ticket
+
+
+POISON = 1.0e30  # written into the flag row of a failing rank's pad (results are flow in pixels / masks in [0, 1])
 
 
 class ShardedPredictor:
@@ -49,7 +62,9 @@ class ShardedPredictor:
     result into ring slot ``i % depth``; ``result(i)`` waits for that gather and returns ``(flow, mask)`` of ALL
     pairs in global order.  A slot is reused ``depth`` submits later (its gather is waited for first).
     A rank whose shard is empty (fewer pairs than ranks) skips ``predict`` and contributes a zero pad, so no rank
-    ever misses the collective."""
+    ever misses the collective.  A rank whose ``predict`` RAISES still joins the collective: its pad carries a poison
+    flag (one extra fp32 row per rank), every rank sees it once the gather completes, and ``result`` / ``wait`` /
+    ``drain`` raise ``ShardFailed`` on all of them -- nobody is left blocked in the all_gather until it times out."""
 
     def __init__(self, predict: Predict, group=None, depth: int = 2):
         self.predict, self.group, self.depth = predict, group, depth
@@ -60,12 +75,12 @@ class ShardedPredictor:
 
     def _buffers(self, slot: int, max_b: int, tail: Tuple[int, ...], like: torch.Tensor) -> dict:
         s = self._slots[slot]
-        shape = (max_b,) + tail
+        shape = (max_b + 1,) + tail  # row max_b = this rank's status row (all POISON when its predict raised)
         if s is None or s["pad"].shape != shape or s["pad"].device != like.device:
             s = dict(
                 pad=torch.zeros(shape, dtype=torch.float32, device=like.device),
-                out=torch.empty((self.world * max_b,) + tail, dtype=torch.float32, device=like.device),
-                work=None, n=0, max_b=max_b,
+                out=torch.empty((self.world * (max_b + 1),) + tail, dtype=torch.float32, device=like.device),
+                work=None, n=0, max_b=max_b, error=None, ticket=-1,
             )
             self._slots[slot] = s
         return s
@@ -76,52 +91,79 @@ class ShardedPredictor:
         n = int(source.shape[0])
         ticket = self._count
         slot = ticket % self.depth
-        if self._slots[slot] is not None and self._slots[slot]["work"] is not None:
-            self._slots[slot]["work"].wait()  # the buffers of `depth` submits ago are free again
-            self._slots[slot]["work"] = None
+        if self._slots[slot] is not None and (self._slots[slot]["work"] is not None or self._slots[slot]["error"] is not None):
+            self._finish(self._slots[slot], False)  # the buffers of `depth` submits ago are free again (a local failure of that submit raises here)
         lo, hi = shard_bounds(n, self.rank, self.world)
         max_b = -(-n // self.world)
+        def default_hw():
+            if out_hw is not None:
+                return tuple(out_hw)
+            return tuple(source.shape[1:3]) if source.shape[-1] == 3 else tuple(source.shape[-2:])
+
+        error = None
         if hi > lo:
-            flow, mask = self.predict(source[lo:hi], target[lo:hi])
+            try:
+                flow, mask = self.predict(source[lo:hi], target[lo:hi])
+            except Exception as exc:  # still join the collective, flagged; raised from result()/wait()/drain() on EVERY rank
+                error = exc
+        if hi > lo and error is None:
             tail = (3,) + tuple(flow.shape[2:])
             s = self._buffers(slot, max_b, tail, flow)
             s["pad"][: hi - lo, :2].copy_(flow)
             s["pad"][: hi - lo, 2].copy_(mask)
+            filled = hi - lo
         else:
-            if out_hw is None:
-                hw = tuple(source.shape[1:3]) if source.shape[-1] == 3 else tuple(source.shape[-2:])
-            else:
-                hw = tuple(out_hw)
-            s = self._buffers(slot, max_b, (3,) + hw, source)
-        if hi - lo < max_b:
-            s["pad"][hi - lo :].zero_()
-        s["n"] = n
+            s = self._buffers(slot, max_b, (3,) + default_hw(), source)
+            filled = 0
+        s["pad"][filled:].zero_()
+        if error is not None:
+            s["pad"][max_b].fill_(POISON)
+        s["n"], s["error"], s["ticket"], s["checked"] = n, error, ticket, False
         s["work"] = dist.all_gather_into_tensor(s["out"], s["pad"], group=self.group, async_op=True)
         self._count += 1
         return ticket
 
-    def wait(self, ticket: int) -> None:
-        """Wait for the gather of ``ticket`` without assembling the result (stream-level on nccl)."""
-        assert self._count - self.depth <= ticket < self._count, "ticket is no longer (or not yet) in the ring"
-        s = self._slots[ticket % self.depth]
+    def _finish(self, s: dict, check: bool) -> None:
+        """Complete the slot's gather; with ``check`` read every rank's status row (one tiny device->host copy) and raise
+        ``ShardFailed`` on all ranks if any of them failed."""
         if s["work"] is not None:
             s["work"].wait()
             s["work"] = None
+        if s["error"] is not None:  # the local failure is known without looking at the buffer
+            err, s["error"] = s["error"], None
+            raise ShardFailed([self.rank], s["ticket"]) from err
+        if check and not s.get("checked", False):
+            stride = s["max_b"] + 1
+            flags = s["out"].view(self.world, stride, -1)[:, s["max_b"], 0]
+            bad = [r for r, v in enumerate(flags.tolist()) if v >= 0.5 * POISON]  # (fp32(1e30) != the Python double 1e30)
+            s["checked"] = True
+            if bad:
+                raise ShardFailed(bad, s["ticket"])
+
+    def wait(self, ticket: int, check: bool = False) -> None:
+        """Wait for the gather of ``ticket`` without assembling the result (stream-level on nccl).  A failure of THIS rank's
+        ``predict`` raises here; ``check=True`` also inspects the other ranks' status rows (a device->host sync)."""
+        assert self._count - self.depth <= ticket < self._count, "ticket is no longer (or not yet) in the ring"
+        self._finish(self._slots[ticket % self.depth], check)
 
     def result(self, ticket: int) -> Tuple[torch.Tensor, torch.Tensor]:
         assert self._count - self.depth <= ticket < self._count, "ticket is no longer (or not yet) in the ring"
         s = self._slots[ticket % self.depth]
-        if s["work"] is not None:
-            s["work"].wait()
-            s["work"] = None
-        full = _unpack(s["out"], s["n"], self.world, s["max_b"])
+        self._finish(s, True)
+        full = _unpack(s["out"], s["n"], self.world, s["max_b"], s["max_b"] + 1)
         return full[:, :2], full[:, 2]
 
     def drain(self) -> None:
+        """Complete every gather in flight; raises ``ShardFailed`` if any rank failed on any of them."""
+        failed = None
         for s in self._slots:
-            if s is not None and s["work"] is not None:
-                s["work"].wait()
-                s["work"] = None
+            if s is not None and (s["work"] is not None or s["error"] is not None):
+                try:
+                    self._finish(s, True)
+                except ShardFailed as exc:
+                    failed = failed or exc
+        if failed is not None:
+            raise failed
 
 
 def gather_results(packed_local: torch.Tensor, n_pairs: int, group=None) -> torch.Tensor:

@@ -7,6 +7,12 @@ workspace, packed weights), captures one call into a ``torch.cuda.CUDAGraph`` (a
 input / output buffers, and afterwards ``__call__`` = two device copies + one graph launch.  Results are bitwise
 those of the eager call (same kernels, same order, same workspace; tests/test_model_gpu.py).
 
+The captured graph holds raw pointers into the workspace and the packed weights of the Engine it was captured on.  That
+Engine is PRIVATE to the GraphedPredictor: eager calls on the same model (another batch size or resolution reallocates the
+shared engine's workspace, ``set_numerics`` drops it) never touch the graph's buffers.  What a replay cannot follow is a
+change of the model's parameters: ``__call__`` compares the parameters' versions and storage with those at capture time and
+raises instead of replaying stale weights.
+
 The returned tensors are the graph's static outputs: they are overwritten by the next call (clone to keep).
 """
 
@@ -26,9 +32,14 @@ class GraphedPredictor:
         self.model, self.norm = model, data_norm_type
         self._src = source_image.clone()
         self._tgt = target_image.clone()
-        eng = model.engine()
-        saved_mb = eng.micro_batches
+        from .engine import Engine
+
+        shared = model._engine
+        eng = self._engine = Engine(model, model.numerics)  # private workspace + packed weights: nothing else ever runs on it
+        if shared is not None:
+            eng.concurrent_heads, eng.fused_tail = shared.concurrent_heads, shared.fused_tail
         eng.micro_batches = 1  # one stream, one host thread: the capture records a single linear launch sequence
+        model._engine = eng
         try:
             side = torch.cuda.Stream(device=source_image.device)
             side.wait_stream(torch.cuda.current_stream(source_image.device))
@@ -41,11 +52,17 @@ class GraphedPredictor:
             with torch.cuda.graph(self.graph):
                 self._out = model.predict_correspondences_batched(self._src, self._tgt, data_norm_type)
         finally:
-            eng.micro_batches = saved_mb
+            model._engine = shared  # eager calls go back to the shared engine (created on demand if there was none)
+        self._weights_key = self._params_key()
+
+    def _params_key(self):
+        return tuple((p._version, p.data_ptr()) for p in self.model.parameters())
 
     def __call__(self, source_image: torch.Tensor, target_image: torch.Tensor) -> UFMOutputInterface:
         if source_image.shape != self._src.shape or source_image.dtype != self._src.dtype or target_image.shape != self._tgt.shape:
             raise ValueError("GraphedPredictor was captured for a different input signature")
+        if self._params_key() != self._weights_key:
+            raise RuntimeError("the model's parameters changed (or moved) after the graph was captured: capture a new GraphedPredictor")
         self._src.copy_(source_image, non_blocking=True)
         self._tgt.copy_(target_image, non_blocking=True)
         self.graph.replay()

@@ -36,12 +36,17 @@ DROP_RULES: Dict[str, Optional[str]] = {
 RENAMES: Dict[str, Optional[str]] = {}
 
 # extra keys a checkpoint may carry without being an error (regular expressions, full match)
+# -- exactly what the reference itself drops before its strict load (ufm.py:203-211) plus BatchNorm's step counter
 ALLOWED_UNEXPECTED: Tuple[str, ...] = (
     r"encoder\.model\.mask_token",
-    r"encoder\.model\.register_tokens",
     r".*\.num_batches_tracked",
-    r".*rope\..*",                       # RoPE caches of the cross-attention variant register as buffers
     r"feature_matching_proj\..*",
+)
+
+# keys that identify an encoder / info-sharing VARIANT this build does not implement: loading such a checkpoint into the
+# plain DINOv2 encoder would run without error and produce wrong outputs, so they raise by name
+UNSUPPORTED_VARIANT_KEYS: Tuple[Tuple[str, str], ...] = (
+    (r"encoder\.model\.register_tokens", "a DINOv2-with-registers encoder (register tokens are not implemented)"),
 )
 
 
@@ -76,6 +81,11 @@ def normalise(state_dict: Mapping[str, torch.Tensor], lightning: bool = False) -
 def check_load_result(missing: Iterable[str], unexpected: Iterable[str], what: str = "checkpoint") -> None:
     """No parameter may be missing (ufm.py:216-217); unexpected keys must be on the allow list."""
     missing = sorted(missing)
+    unexpected = list(unexpected)
+    for pat, what_variant in UNSUPPORTED_VARIANT_KEYS:
+        hit = [k for k in unexpected if re.fullmatch(pat, k)]
+        if hit:
+            raise RuntimeError(f"{what} holds {hit[0]}: it was saved from {what_variant}; loading it into this model would run and give wrong outputs")
     bad_unexpected = sorted(k for k in unexpected if not any(re.fullmatch(p, k) for p in ALLOWED_UNEXPECTED))
     if missing or bad_unexpected:
         def head(keys: List[str]) -> str:

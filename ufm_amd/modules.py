@@ -296,7 +296,9 @@ class AdaptorSpec(_Holder):
             self.required_channels = 1
             self.kinds, self.scale, self.shift = [0], [1.0], [0.0]
             ctype = kw.get("confidence_type", "exp")
-            self.confidence_type = {"exp": 0, "sigmoid": 1}.get(ctype, 2)
+            if ctype not in ("exp", "sigmoid", "identity"):
+                raise ValueError(f"ConfidenceAdaptor: unknown confidence_type {ctype!r} (known: 'exp', 'sigmoid', 'identity')")
+            self.confidence_type = {"exp": 0, "sigmoid": 1, "identity": 2}[ctype]
             self.vmin, self.vmax = float(kw.get("vmin", 1.0)), float(kw.get("vmax", float("inf")))
         else:
             raise NotImplementedError(f"adaptor {cls_name} has no call site on the UFM inference path (ufm.py:644-660)")
