@@ -50,6 +50,32 @@ MFMA_PEAKS = {"ufm_gemm_bf16": PEAK_BF16_TFLOPS, "ufm_attention_bf16": PEAK_BF16
               "ufm_gemm_bf16x3": PEAK_BF16X3_TFLOPS, "ufm_attention_bf16x3": PEAK_BF16X3_TFLOPS}
 
 
+def meta_work(m) -> float:
+    """A launch's algorithmic work: KernelTimer metas are a number or (number, shape tag)."""
+    if not m:
+        return 0.0
+    return float(m[0]) if isinstance(m, tuple) else float(m)
+
+
+def per_shape_table(d, peak_tflops: float):
+    """GEMM launches of one instrumented step grouped by shape tag (QKV / proj / fc1 / fc2 of the encoder and of the
+    info-sharing blocks differ in M, N, K and epilogue): launches, total and average time, TFLOP/s, fraction of peak."""
+    rows = {}
+    for (name, e0, e1, meta) in d:
+        if not isinstance(meta, tuple):
+            continue
+        r = rows.setdefault(meta[1], {"launches": 0, "ms": 0.0, "gflop": 0.0})
+        r["launches"] += 1
+        r["ms"] += e0.elapsed_time(e1)
+        r["gflop"] += meta[0] / 1e9
+    out = {}
+    for tag, r in sorted(rows.items(), key=lambda kv: -kv[1]["ms"]):
+        tf = r["gflop"] / r["ms"] if r["ms"] > 0 else 0.0  # GFLOP / ms = TFLOP/s
+        out[tag] = {"launches": r["launches"], "ms_per_step": round(r["ms"], 4), "avg_launch_us": round(1e3 * r["ms"] / r["launches"], 2),
+                    "tflops": round(tf, 1), "frac": round(tf / peak_tflops, 4)}
+    return out
+
+
 def host_cores() -> int:
     """Threads the CPU baseline may use: the cgroup CPU quota if one is set, else the affinity mask,
     capped at 16 (a 1-GPU box's CPU share; os.cpu_count() reports the whole 256-thread host)."""
@@ -245,15 +271,18 @@ def main():
         hip.TIMER = hip.KernelTimer()
         model.predict_correspondences_batched(src, tgt)
         summ = hip.TIMER.summary()
+        records = hip.TIMER.records
         hip.TIMER = None
         kernels = {}
         for name, d in summ.items():
-            work = sum(m for m in d["metas"] if m)
+            work = sum(meta_work(m) for m in d["metas"])
             entry = {"launches": d["launches"], "ms_per_step": d["ms"], "avg_launch_us": 1e3 * d["ms"] / d["launches"]}
             if name in MFMA_PEAKS:
                 peak = MFMA_PEAKS[name]
                 entry.update(bound="mfma", algorithmic_gflop=work / 1e9, achieved=work / (d["ms"] * 1e-3) / 1e12, peak=peak, unit="TFLOP/s")
                 entry["frac"] = entry["achieved"] / peak
+                if name in ("ufm_gemm_bf16", "ufm_gemm_bf16x3"):
+                    entry["per_shape"] = per_shape_table([r for r in records if r[0] == name], peak)
             elif work:
                 entry.update(bound="hbm", algorithmic_gb=work / 1e9, achieved=work / (d["ms"] * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s")
                 entry["frac"] = entry["achieved"] / PEAK_HBM_GBS
@@ -370,13 +399,16 @@ def main():
             hip.TIMER = hip.KernelTimer()
             model.predict_correspondences_batched(src, tgt)
             summ = hip.TIMER.summary()
+            records = hip.TIMER.records
             hip.TIMER = None
             pk = {}
             for name, d in summ.items():
                 if name in MFMA_PEAKS:
-                    work = sum(m for m in d["metas"] if m)
+                    work = sum(meta_work(m) for m in d["metas"])
                     pk[name] = {"launches": d["launches"], "ms_per_step": d["ms"], "achieved": work / (d["ms"] * 1e-3) / 1e12, "peak": MFMA_PEAKS[name],
                                 "unit": "TFLOP/s (algorithmic)", "frac": work / (d["ms"] * 1e-3) / 1e12 / MFMA_PEAKS[name]}
+                    if name == "ufm_gemm_bf16x3":
+                        pk[name]["per_shape"] = per_shape_table([r for r in records if r[0] == name], MFMA_PEAKS[name])
                 else:
                     pk[name] = {"launches": d["launches"], "ms_per_step": d["ms"]}
             pm["kernels"] = pk

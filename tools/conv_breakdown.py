@@ -19,7 +19,8 @@ m.predict_correspondences_batched(src, tgt)
 torch.cuda.synchronize()
 rows = collections.defaultdict(lambda: [0, 0.0])
 for name, e0, e1, meta in hip.TIMER.records:
-    k = (name, round(meta / 1e9, 2) if meta else 0)
+    w = meta[0] if isinstance(meta, tuple) else meta  # GEMM metas are (flops, shape tag)
+    k = (name, round(w / 1e9, 2) if w else 0)
     rows[k][0] += 1
     rows[k][1] += e0.elapsed_time(e1)
 hip.TIMER = None

@@ -178,7 +178,8 @@ def resize_antialias(img: torch.Tensor, layout: int, B: int, H: int, W: int, sca
 
 
 def gemm_bf16(A, W, M, N, K, out, *, bias=None, act=ACT_NONE, gamma=None, res=None, ldres=0, res_row_mod=0, lda=None, ldw=None, ldo=None, out_row_group=0):
-    _t("ufm_gemm_bf16", 2.0 * M * N * K)
+    _t("ufm_gemm_bf16", (2.0 * M * N * K, f"M{M} N{N} K{K} " + ("f32 += (read-modify-write)" if (out.dtype == torch.float32 and res is not None and res_row_mod == 0) else
+                                                             "f32 out" if out.dtype == torch.float32 else "bf16 out" + (" GELU" if act == ACT_GELU else ""))))
     _check(
         lib().ufm_gemm_bf16(_p(A), lda or K, _p(W), ldw or K, M, N, K, _p(bias), act, _p(gamma), _p(res), ldres or N, res_row_mod, _p(out), _dt(out), ldo or N, out_row_group, _stream()),
         "ufm_gemm_bf16",
@@ -213,7 +214,7 @@ def gemm_x3(A, W, M, N, K, out, zero_page, *, bias=None, act=ACT_NONE, gamma=Non
     or fp32 (M, N) with the optional fp32 residual `res` (may be `out`)."""
     split_out = out.dtype == torch.bfloat16
     assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and (split_out or out.dtype == torch.float32)
-    _t("ufm_gemm_bf16x3", 2.0 * M * N * K)
+    _t("ufm_gemm_bf16x3", (2.0 * M * N * K, f"M{M} N{N} K{K} " + ("split out" + (" GELU" if act == ACT_GELU else "") if split_out else "f32 += (read-modify-write)" if res is not None else "f32 out")))
     _check(lib().ufm_gemm_bf16x3(_p(A), _p(W), M, N, K, _p(bias), act, _p(gamma), _p(res), _p(out), BF16X2 if split_out else F32, _p(zero_page), _stream()), "ufm_gemm_bf16x3")
 
 
