@@ -129,6 +129,16 @@ int ufm_layernorm(const float* x, int ldx, const int32_t* row_index, int rows_ou
                   const float* weight, const float* bias, float eps, void* out, int out_dtype,
                   int ldo, void* stream);
 
+/* Residual update fused in front of the LayerNorm:  x[r, :] += gamma[:] * branch[r, :]  (fp32 math; branch = the bf16
+ * output of the preceding Attention.proj / Mlp.fc2 Linear, gamma = LayerScale or NULL), x is written back, then
+ * out[r, :] = LayerNorm(x[r, :]) as ufm_layernorm.  This is the reference's own GPU arithmetic for
+ * `x = x + ls(branch)` under bf16 autocast (models/base.py:273: the Linear returns bf16, the LayerScale multiply and the
+ * add run in fp32 on the fp32 residual stream; [U] Block.forward), and it moves the residual stream's fp32
+ * read-modify-write out of the GEMM epilogue into this HBM-bound kernel. */
+int ufm_add_layernorm(float* x, int ldx, const uint16_t* branch, int ldb, const float* gamma, int rows, int D,
+                      const float* weight, const float* bias, float eps, void* out, int out_dtype, int ldo,
+                      void* stream);
+
 /* out[r, :] = src[(r % src_rows), :]  for the rows listed: fills the cls-token rows
  * (cls_token + pos_embed[0]) of the token buffer: out row = g*(group)+0.  ([U] DINOv2 prepare_tokens) */
 int ufm_fill_rows(float* out, int ldo, int n_groups, int group_stride_rows, const float* src, int D,

@@ -218,6 +218,30 @@ def test_layernorm(hip, D, out_bf16):
     assert err <= (3e-2 if out_bf16 else 2e-5)
 
 
+@pytest.mark.parametrize("D", [128, 768, 1024])
+@pytest.mark.parametrize("out_kind", ["bf16", "f32", "split"])
+@pytest.mark.parametrize("use_gamma", [False, True])
+def test_add_layernorm(hip, D, out_kind, use_gamma):
+    """ufm_add_layernorm: x += gamma * branch (fp32 math on the bf16 branch, x written back), then LayerNorm(x)."""
+    rows = 301
+    x = rnd(rows, D, seed=1, scale=2.0)
+    br = bf16r(rnd(rows, D, seed=2))
+    gamma = 1 + rnd(D, seed=3, scale=0.2) if use_gamma else None
+    w, b = 1 + rnd(D, seed=4, scale=0.1), rnd(D, seed=5, scale=0.1)
+    x_new = x + (gamma * br if gamma is not None else br)  # fp32, mul then add: what the kernel does (-ffp-contract=off)
+    ref = F.layer_norm(x_new.double(), (D,), w.double(), b.double(), 1e-6)
+    xd = x.to(DEV).clone()
+    if out_kind == "split":
+        out = torch.zeros(2, rows, D, device=DEV, dtype=torch.bfloat16)
+    else:
+        out = torch.zeros(rows, D, device=DEV, dtype=torch.bfloat16 if out_kind == "bf16" else torch.float32)
+    hip.add_layernorm(xd, D, br.to(DEV).bfloat16(), gamma.to(DEV) if gamma is not None else None, rows, D, w.to(DEV), b.to(DEV), 1e-6, out, split=out_kind == "split")
+    assert torch.equal(xd.cpu(), x_new), "the residual stream must hold exactly x + gamma * branch (fp32)"
+    got = (out[0].float() + out[1].float()) if out_kind == "split" else out.float()
+    err = (got.cpu().double() - ref).abs().max().item()
+    assert err <= (3e-2 if out_kind == "bf16" else 2e-5), err
+
+
 # ----------------------------------------------------------------------------- attention
 def attn_ref(qkv, B, N, H, scale):
     q, k, v = qkv.double().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)

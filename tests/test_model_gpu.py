@@ -131,6 +131,31 @@ def test_tiny_fast_mode_tolerance(env):
     assert e_fast_ac.mean().item() <= 1.5 * e_ac.mean().item() + 1e-4 and e_fast_ac.max().item() <= 1.5 * e_ac.max().item() + 1e-3
 
 
+def test_fast_mode_deferred_residual_update_matches_the_in_epilogue_form(env):
+    """ "fast" applies x += gamma * branch in the LayerNorm launch that follows (the branch rounded to bf16 first: the
+    reference's autocast arithmetic) instead of inside the proj / fc2 GEMM epilogue (fp32 accumulator straight into the
+    stream).  Both forms must stay inside the fast-mode tolerance of the oracle, and differ from each other only by that
+    bf16 rounding of the branch outputs."""
+    oracle, prod = build_pair(env)
+    prod.set_numerics("fast")
+    src, tgt = u8((2, 56, 56, 3), 1), u8((2, 56, 56, 3), 2)
+    o = oracle.predict_correspondences_batched(src, tgt)
+    eng = prod.engine()
+    assert eng.defer_residual is True
+    a = prod.predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
+    fa, ma = a.flow.flow_output.clone(), a.covisibility.mask.clone()
+    eng.defer_residual = False
+    b = prod.predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
+    eng.defer_residual = True
+    rng = o.flow.flow_output.abs().max().item()
+    da = (fa.cpu() - o.flow.flow_output).abs().max().item()
+    db = (b.flow.flow_output.cpu() - o.flow.flow_output).abs().max().item()
+    dab = (fa - b.flow.flow_output).abs().max().item()
+    print(f"fast, tiny: deferred vs oracle {da:.3g}, in-epilogue vs oracle {db:.3g}, deferred vs in-epilogue {dab:.3g} (range {rng:.3g})")
+    assert da <= 0.013 * rng and db <= 0.013 * rng and dab <= 0.013 * rng
+    assert (ma - b.covisibility.mask).abs().max().item() <= 0.01
+
+
 def test_forward_lower_level_api_and_errors(env):
     ufm_amd, R = env
     oracle, prod = build_pair(env)

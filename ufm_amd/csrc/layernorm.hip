@@ -2,6 +2,10 @@
 // registers (mean, then centred variance -- the same association torch uses), wave reduction by
 // DPP/shuffle; HBM-bound (reads D*4 B, writes D*2 or D*4 B per row).  An optional row-index table
 // turns the kernel into gather+LN so "drop cls / reorder views" costs no extra pass.
+// ADD (ufm_add_layernorm): the residual update of the preceding branch is fused in front of the normalisation,
+//   x[row] += gamma * branch[row]   (branch: the bf16 output of the proj / fc2 Linear, gamma: LayerScale, fp32 math),
+// x is written back -- the fp32 read-modify-write of the residual stream leaves the GEMM epilogue (where all 256 CUs
+// hit HBM at once with the matrix cores idle) for this HBM-bound kernel, and the GEMM gets the cheap bf16 store.
 #include "common.h"
 
 namespace {
@@ -17,20 +21,46 @@ __device__ __forceinline__ float wave_sum(float v) {
 // D == VPL*256 known at compile time: the row is held in VPL float4 registers across the three passes.  (With a
 // run-time D the guarded loops below compile to 14 VGPRs: hipcc re-reads the row from memory in every pass --
 // 54 us vs 24 us for 21920 x 1024, found with tools/lab/ln_lab.hip.)
-template <int OUT_BF16, int VPL>
+struct LnAdd {  // ADD: x[row] += gamma * branch[row] before the statistics (row_index must be null)
+    const uint16_t* branch;  // bf16 [rows][ldb]
+    const float* gamma;      // fp32 [D] or null (= 1)
+    int ldb;
+};
+
+__device__ __forceinline__ f32x4 ln_add4(const f32x4& x, const uint16_t* br, const float* gamma, int c4) {
+    const u32x2 a = *(const u32x2*)(br + c4);
+    f32x4 g = {1.f, 1.f, 1.f, 1.f};
+    if (gamma) g = *(const f32x4*)(gamma + c4);
+    f32x4 r;
+    r[0] = x[0] + g[0] * __uint_as_float(a[0] << 16);
+    r[1] = x[1] + g[1] * __uint_as_float(a[0] & 0xffff0000u);
+    r[2] = x[2] + g[2] * __uint_as_float(a[1] << 16);
+    r[3] = x[3] + g[3] * __uint_as_float(a[1] & 0xffff0000u);
+    return r;
+}
+
+template <int OUT_BF16, int VPL, bool ADD = false>
 __global__ __launch_bounds__(256) void layernorm_kernel_fixed(const float* __restrict__ x, int ldx,
                                                               const int32_t* __restrict__ row_index, int rows_out,
                                                               const float* __restrict__ w, const float* __restrict__ b,
-                                                              float eps, void* out, int ldo) {
+                                                              float eps, void* out, int ldo, LnAdd add) {
     constexpr int D = VPL * 256;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows_out) return;
-    const int in_row = row_index ? row_index[row] : row;
+    const int in_row = (!ADD && row_index) ? row_index[row] : row;
     const float* xr = x + (size_t)in_row * ldx;
     f32x4 v[VPL];
 #pragma unroll
     for (int i = 0; i < VPL; ++i) v[i] = *(const f32x4*)(xr + (lane + i * 64) * 4);
+    if (ADD) {
+        const uint16_t* br = add.branch + (size_t)row * add.ldb;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            v[i] = ln_add4(v[i], br, add.gamma, (lane + i * 64) * 4);
+            *(f32x4*)(const_cast<float*>(xr) + (lane + i * 64) * 4) = v[i];
+        }
+    }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
@@ -73,15 +103,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel_fixed(const float* __res
     }
 }
 
-template <int OUT_BF16>
+template <int OUT_BF16, bool ADD = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx,
                                                         const int32_t* __restrict__ row_index, int rows_out,
                                                         int D, const float* __restrict__ w,
-                                                        const float* __restrict__ b, float eps, void* out, int ldo) {
+                                                        const float* __restrict__ b, float eps, void* out, int ldo, LnAdd add) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows_out) return;
-    const int in_row = row_index ? row_index[row] : row;
+    const int in_row = (!ADD && row_index) ? row_index[row] : row;
     const float* xr = x + (size_t)in_row * ldx;
     const int nvec = D >> 2;
     f32x4 v[MAX_VPL];
@@ -91,6 +121,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         const int c = lane + i * 64;
         if (c < nvec) {
             v[i] = *(const f32x4*)(xr + c * 4);
+            if (ADD) {
+                v[i] = ln_add4(v[i], add.branch + (size_t)row * add.ldb, add.gamma, c * 4);
+                *(f32x4*)(const_cast<float*>(xr) + c * 4) = v[i];
+            }
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
     }
@@ -151,17 +185,11 @@ __global__ __launch_bounds__(256) void fill_rows_kernel(float* out, int ldo, int
 
 }  // namespace
 
-extern "C" int ufm_layernorm(const float* x, int ldx, const int32_t* row_index, int rows_out, int D,
-                             const float* weight, const float* bias, float eps, void* out, int out_dtype,
-                             int ldo, void* stream) {
-    UFM_REQUIRE(x && weight && bias && out, "ufm_layernorm: null pointer");
-    UFM_REQUIRE(rows_out > 0, "ufm_layernorm: rows_out=%d", rows_out);
-    UFM_REQUIRE(D % 4 == 0 && D <= MAX_VPL * 256 && D > 0, "ufm_layernorm: D=%d must be a multiple of 4 and <= %d", D, MAX_VPL * 256);
-    UFM_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && ldx >= D && ldo >= D, "ufm_layernorm: bad ldx/ldo %d/%d", ldx, ldo);
-    UFM_REQUIRE(out_dtype == UFM_F32 || out_dtype == UFM_BF16 || out_dtype == UFM_BF16X2, "ufm_layernorm: bad out_dtype");
+template <bool ADD>
+static void launch_layernorm(const float* x, int ldx, const int32_t* row_index, int rows_out, int D, const float* weight,
+                             const float* bias, float eps, void* out, int out_dtype, int ldo, LnAdd add, hipStream_t st) {
     dim3 grid((rows_out + 3) / 4), block(256);
-    hipStream_t st = (hipStream_t)stream;
-#define UFM_LN_FIXED(OUT, VPL) hipLaunchKernelGGL((layernorm_kernel_fixed<OUT, VPL>), grid, block, 0, st, x, ldx, row_index, rows_out, weight, bias, eps, out, ldo)
+#define UFM_LN_FIXED(OUT, VPL) hipLaunchKernelGGL((layernorm_kernel_fixed<OUT, VPL, ADD>), grid, block, 0, st, x, ldx, row_index, rows_out, weight, bias, eps, out, ldo, add)
 #define UFM_LN_BY_VPL(OUT)                  \
     switch (D / 256) {                      \
         case 1: UFM_LN_FIXED(OUT, 1); break; \
@@ -176,14 +204,39 @@ extern "C" int ufm_layernorm(const float* x, int ldx, const int32_t* row_index, 
     if (D % 256 == 0) {
         if (out_dtype == UFM_BF16X2) { UFM_LN_BY_VPL(2) } else if (out_dtype == UFM_BF16) { UFM_LN_BY_VPL(1) } else { UFM_LN_BY_VPL(0) }
     } else if (out_dtype == UFM_BF16X2)
-        hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, x, ldx, row_index, rows_out, D, weight, bias, eps, out, ldo);
+        hipLaunchKernelGGL((layernorm_kernel<2, ADD>), grid, block, 0, st, x, ldx, row_index, rows_out, D, weight, bias, eps, out, ldo, add);
     else if (out_dtype == UFM_BF16)
-        hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, x, ldx, row_index, rows_out, D, weight, bias, eps, out, ldo);
+        hipLaunchKernelGGL((layernorm_kernel<1, ADD>), grid, block, 0, st, x, ldx, row_index, rows_out, D, weight, bias, eps, out, ldo, add);
     else
-        hipLaunchKernelGGL(layernorm_kernel<0>, grid, block, 0, st, x, ldx, row_index, rows_out, D, weight, bias, eps, out, ldo);
+        hipLaunchKernelGGL((layernorm_kernel<0, ADD>), grid, block, 0, st, x, ldx, row_index, rows_out, D, weight, bias, eps, out, ldo, add);
 #undef UFM_LN_BY_VPL
 #undef UFM_LN_FIXED
+}
+
+extern "C" int ufm_layernorm(const float* x, int ldx, const int32_t* row_index, int rows_out, int D,
+                             const float* weight, const float* bias, float eps, void* out, int out_dtype,
+                             int ldo, void* stream) {
+    UFM_REQUIRE(x && weight && bias && out, "ufm_layernorm: null pointer");
+    UFM_REQUIRE(rows_out > 0, "ufm_layernorm: rows_out=%d", rows_out);
+    UFM_REQUIRE(D % 4 == 0 && D <= MAX_VPL * 256 && D > 0, "ufm_layernorm: D=%d must be a multiple of 4 and <= %d", D, MAX_VPL * 256);
+    UFM_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && ldx >= D && ldo >= D, "ufm_layernorm: bad ldx/ldo %d/%d", ldx, ldo);
+    UFM_REQUIRE(out_dtype == UFM_F32 || out_dtype == UFM_BF16 || out_dtype == UFM_BF16X2, "ufm_layernorm: bad out_dtype");
+    launch_layernorm<false>(x, ldx, row_index, rows_out, D, weight, bias, eps, out, out_dtype, ldo, LnAdd{nullptr, nullptr, 0}, (hipStream_t)stream);
     UFM_CHECK_LAUNCH("ufm_layernorm");
+    return UFM_OK;
+}
+
+extern "C" int ufm_add_layernorm(float* x, int ldx, const uint16_t* branch, int ldb, const float* gamma, int rows, int D,
+                                 const float* weight, const float* bias, float eps, void* out, int out_dtype, int ldo,
+                                 void* stream) {
+    UFM_REQUIRE(x && branch && weight && bias && out, "ufm_add_layernorm: null pointer");
+    UFM_REQUIRE(rows > 0, "ufm_add_layernorm: rows=%d", rows);
+    UFM_REQUIRE(D % 4 == 0 && D <= MAX_VPL * 256 && D > 0, "ufm_add_layernorm: D=%d must be a multiple of 4 and <= %d", D, MAX_VPL * 256);
+    UFM_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && ldb % 4 == 0 && ldx >= D && ldo >= D && ldb >= D, "ufm_add_layernorm: bad ldx/ldb/ldo %d/%d/%d", ldx, ldb, ldo);
+    UFM_REQUIRE(((uintptr_t)branch % 8) == 0 && ((uintptr_t)x % 16) == 0, "ufm_add_layernorm: misaligned pointer");
+    UFM_REQUIRE(out_dtype == UFM_F32 || out_dtype == UFM_BF16 || out_dtype == UFM_BF16X2, "ufm_add_layernorm: bad out_dtype");
+    launch_layernorm<true>(x, ldx, nullptr, rows, D, weight, bias, eps, out, out_dtype, ldo, LnAdd{branch, gamma, ldb}, (hipStream_t)stream);
+    UFM_CHECK_LAUNCH("ufm_add_layernorm");
     return UFM_OK;
 }
 

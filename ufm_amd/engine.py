@@ -165,6 +165,9 @@ class Engine:
         self._tls = threading.local()  # .ns = workspace namespace of the micro-batch this thread is running
         self.micro_batches = 2  # >1: the batch is split into micro-batches that run concurrently on separate HIP streams
         self._streams: List[torch.cuda.Stream] = []
+        # "fast": the residual stream's fp32 read-modify-write is done by the next LayerNorm launch (ufm_add_layernorm) instead
+        # of the proj / fc2 GEMM epilogues; False = in the GEMM epilogue (the fp32 accumulator goes straight into the stream)
+        self.defer_residual = True
         self.fused_tail = True  # ufm_dpt_tail_fused where the head has the UFM-Base tail shape (bit-identical to the unfused path)
         # DPT heads on separate HIP streams: None = automatic (yes for a single-stream forward -- one pair: 9.84 -> 8.97 ms
         # graph replay, the small-grid layers of one head fill the other's tails -- no inside a micro-batch worker, where the
@@ -355,22 +358,45 @@ class Engine:
         return t
 
     # ------------------------------------------------------------------ transformer
-    def _blocks(self, blocks: List[_Blk], x, Bseq: int, N: int, D: int, heads: int, on_block):
+    def _blocks(self, blocks: List[_Blk], x, Bseq: int, N: int, D: int, heads: int, on_block, needs_x=lambda i: True):
+        """The transformer blocks on the fp32 residual stream ``x`` (updated in place).  ``needs_x(i)``: block i's output is
+        read by ``on_block`` (or is the last one), so its residual update may not stay pending.
+
+        "fast" with ``defer_residual``: proj / fc2 store their bf16 branch output (the cheap GEMM epilogue) and the NEXT
+        LayerNorm launch applies ``x += gamma * branch`` in fp32 before normalising (ufm_add_layernorm) -- the reference's
+        own arithmetic under bf16 autocast (the Linear returns bf16; LayerScale and the add run in fp32), with the residual
+        stream's read-modify-write moved out of the GEMM epilogue, where all CUs hit HBM at once with the matrix cores idle."""
         M = Bseq * N
         x3 = self.trunk_x3
         tb = (lambda name, cols: self.buf(name + "_x2", (2, M, cols), torch.bfloat16)) if x3 else (lambda name, cols: self.buf(name, (M, cols), self.adt))
         xn, qkv, ao, hid = tb("xn", D), tb("qkv", 3 * D), tb("ao", D), tb("hid", blocks[0].fc1.n)
+        defer = self.numerics == "fast" and self.defer_residual
+        br = self.buf("branch", (M, D), torch.bfloat16) if defer else None
+        pending = False  # x still lacks gamma * br of the previous block's fc2
+        pend_gamma = None
         for i, w in enumerate(blocks):
-            hip.layernorm(x, D, None, M, D, w.n1w, w.n1b, 1e-6, xn, split=x3)
+            if pending:
+                hip.add_layernorm(x, D, br, pend_gamma, M, D, w.n1w, w.n1b, 1e-6, xn)
+                pending = False
+            else:
+                hip.layernorm(x, D, None, M, D, w.n1w, w.n1b, 1e-6, xn, split=x3)
             self.linear(xn, w.qkv, M, qkv, gamma=w.qscale)
             if x3:
                 hip.attention_x3(qkv, ao, Bseq, N, heads, 0.125)
             else:
                 hip.attention(qkv, ao, Bseq, N, heads, 0.0 if w.qscale is not None else 0.125)
-            self.linear(ao, w.proj, M, x, gamma=w.ls1, res=x)
-            hip.layernorm(x, D, None, M, D, w.n2w, w.n2b, 1e-6, xn, split=x3)
+            if defer:
+                self.linear(ao, w.proj, M, br)
+                hip.add_layernorm(x, D, br, w.ls1, M, D, w.n2w, w.n2b, 1e-6, xn)
+            else:
+                self.linear(ao, w.proj, M, x, gamma=w.ls1, res=x)
+                hip.layernorm(x, D, None, M, D, w.n2w, w.n2b, 1e-6, xn, split=x3)
             self.linear(xn, w.fc1, M, hid, act=hip.ACT_GELU)
-            self.linear(hid, w.fc2, M, x, gamma=w.ls2, res=x)
+            if defer and i + 1 < len(blocks) and not needs_x(i):
+                self.linear(hid, w.fc2, M, br)
+                pending, pend_gamma = True, w.ls2
+            else:
+                self.linear(hid, w.fc2, M, x, gamma=w.ls2, res=x)
             on_block(i, x)
 
     def _encode(self, patches, B2: int, H: int, W: int):
@@ -652,7 +678,7 @@ class Engine:
                 lvl0 = self.level_ln(xx, D, idx["enc_v1"], B * Np, nw, nb, "lvl0")
 
         blocks = self.enc_blocks[: self.enc_indices[-1] + 1]  # blocks past the last returned index never matter
-        self._blocks(blocks, x, n_enc, N, D, self.enc_heads, on_enc)
+        self._blocks(blocks, x, n_enc, N, D, self.enc_heads, on_enc, needs_x=lambda i: (self.refine and i == self.enc_indices[0]) or i == self.enc_indices[-1])
 
         # ---- info sharing: joint attention over the 2*Np tokens of each pair ----
         M2 = B * 2 * Np
@@ -677,7 +703,7 @@ class Engine:
             if i in self.info_indices:
                 inter.append(self.level_ln(yy, Di, idx["info_v1"], B * Np, inw, inb, f"lvl_i{len(inter)}"))
 
-        self._blocks(self.info_blocks, y, B, 2 * Np, Di, self.info_heads, on_info)
+        self._blocks(self.info_blocks, y, B, 2 * Np, Di, self.info_heads, on_info, needs_x=lambda i: i in self.info_indices)
         if len(inter) != 2:
             raise ValueError("info_sharing.indices must name two blocks (ufm.py:605-606 reads intermediates [0] and [1])")
         lvl3 = self.level_ln(y, Di, idx["info_v1"], B * Np, inw, inb, "lvl3")

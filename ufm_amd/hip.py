@@ -39,6 +39,7 @@ SIGNATURES = {
     "ufm_warp_bilinear": [_vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _f, _vp, _vp],
     "ufm_dpt_tail_fused": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "ufm_layernorm": [_vp, _i, _vp, _i, _i, _vp, _vp, _f, _vp, _i, _i, _vp],
+    "ufm_add_layernorm": [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _f, _vp, _i, _i, _vp],
     "ufm_fill_rows": [_vp, _i, _i, _i, _vp, _i, _vp],
     "ufm_add_rows": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp],
     "ufm_attention_bf16": [_vp, _vp, _i, _i, _i, _f, _vp],
@@ -190,6 +191,13 @@ def layernorm(x, ldx, row_index, rows_out, D, weight, bias, eps, out, ldo=None, 
     """split=True: `out` is a (2, rows_out, D) bf16 tensor in the UFM_BF16X2 format."""
     _t("ufm_layernorm", rows_out * D * (4.0 + (4 if split else out.element_size())))
     _check(lib().ufm_layernorm(_p(x), ldx, _p(row_index), rows_out, D, _p(weight), _p(bias), eps, _p(out), BF16X2 if split else _dt(out), ldo or D, _stream()), "ufm_layernorm")
+
+
+def add_layernorm(x, ldx, branch, gamma, rows, D, weight, bias, eps, out, ldo=None, split=False):
+    """x[r] += gamma * branch[r] (x updated in place), then out = LayerNorm(x).  branch: bf16 (rows, D)."""
+    _t("ufm_layernorm", rows * D * (4.0 + 2.0 + 4.0 + (4 if split else out.element_size())))
+    assert branch.dtype == torch.bfloat16 and x.dtype == torch.float32
+    _check(lib().ufm_add_layernorm(_p(x), ldx, _p(branch), branch.shape[-1], _p(gamma), rows, D, _p(weight), _p(bias), eps, _p(out), BF16X2 if split else _dt(out), ldo or D, _stream()), "ufm_add_layernorm")
 
 
 def fill_rows(out, ldo, n_groups, group_stride_rows, src, D):
