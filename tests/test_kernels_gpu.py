@@ -239,7 +239,7 @@ def test_add_layernorm(hip, D, out_kind, use_gamma):
     assert torch.equal(xd.cpu(), x_new), "the residual stream must hold exactly x + gamma * branch (fp32)"
     got = (out[0].float() + out[1].float()) if out_kind == "split" else out.float()
     err = (got.cpu().double() - ref).abs().max().item()
-    assert err <= (3e-2 if out_kind == "bf16" else 2e-5), err
+    assert err <= (3e-2 if out_kind == "bf16" else 4e-5), err  # split output: 2^-17 relative on |y| <~ 4
 
 
 # ----------------------------------------------------------------------------- attention

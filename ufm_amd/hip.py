@@ -195,7 +195,7 @@ def layernorm(x, ldx, row_index, rows_out, D, weight, bias, eps, out, ldo=None, 
 
 def add_layernorm(x, ldx, branch, gamma, rows, D, weight, bias, eps, out, ldo=None, split=False):
     """x[r] += gamma * branch[r] (x updated in place), then out = LayerNorm(x).  branch: bf16 (rows, D)."""
-    _t("ufm_layernorm", rows * D * (4.0 + 2.0 + 4.0 + (4 if split else out.element_size())))
+    _t("ufm_add_layernorm", rows * D * (4.0 + 2.0 + 4.0 + (4 if split else out.element_size())))
     assert branch.dtype == torch.bfloat16 and x.dtype == torch.float32
     _check(lib().ufm_add_layernorm(_p(x), ldx, _p(branch), branch.shape[-1], _p(gamma), rows, D, _p(weight), _p(bias), eps, _p(out), BF16X2 if split else _dt(out), ldo or D, _stream()), "ufm_add_layernorm")
 
