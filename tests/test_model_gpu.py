@@ -132,21 +132,21 @@ def test_tiny_fast_mode_tolerance(env):
 
 
 def test_fast_mode_deferred_residual_update_matches_the_in_epilogue_form(env):
-    """ "fast" applies x += gamma * branch in the LayerNorm launch that follows (the branch rounded to bf16 first: the
-    reference's autocast arithmetic) instead of inside the proj / fc2 GEMM epilogue (fp32 accumulator straight into the
-    stream).  Both forms must stay inside the fast-mode tolerance of the oracle, and differ from each other only by that
-    bf16 rounding of the branch outputs."""
+    """Engine.defer_residual (off by default: measured neutral in time, slightly worse in accuracy) applies x += gamma *
+    branch in the LayerNorm launch that follows (the branch rounded to bf16 first: the reference's autocast arithmetic)
+    instead of inside the proj / fc2 GEMM epilogue (fp32 accumulator straight into the stream).  Both forms must stay
+    inside the fast-mode tolerance of the oracle, and differ from each other only by that bf16 rounding."""
     oracle, prod = build_pair(env)
     prod.set_numerics("fast")
     src, tgt = u8((2, 56, 56, 3), 1), u8((2, 56, 56, 3), 2)
     o = oracle.predict_correspondences_batched(src, tgt)
     eng = prod.engine()
-    assert eng.defer_residual is True
+    assert eng.defer_residual is False
+    eng.defer_residual = True
     a = prod.predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
     fa, ma = a.flow.flow_output.clone(), a.covisibility.mask.clone()
     eng.defer_residual = False
     b = prod.predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
-    eng.defer_residual = True
     rng = o.flow.flow_output.abs().max().item()
     da = (fa.cpu() - o.flow.flow_output).abs().max().item()
     db = (b.flow.flow_output.cpu() - o.flow.flow_output).abs().max().item()

@@ -165,9 +165,13 @@ class Engine:
         self._tls = threading.local()  # .ns = workspace namespace of the micro-batch this thread is running
         self.micro_batches = 2  # >1: the batch is split into micro-batches that run concurrently on separate HIP streams
         self._streams: List[torch.cuda.Stream] = []
-        # "fast": the residual stream's fp32 read-modify-write is done by the next LayerNorm launch (ufm_add_layernorm) instead
-        # of the proj / fc2 GEMM epilogues; False = in the GEMM epilogue (the fp32 accumulator goes straight into the stream)
-        self.defer_residual = True
+        # "fast", optional: the residual stream's fp32 read-modify-write is done by the next LayerNorm launch
+        # (ufm_add_layernorm) instead of the proj / fc2 GEMM epilogues.  Measured (tools/lab/ab_engine.py, interleaved, same
+        # box, B=8 518^2): the GEMM family rises 0.327 -> 0.346 of peak but the step does not move (38.76 vs 38.91 ms with two
+        # micro-batch streams, 41.43 vs 40.94 single-stream) -- the same bytes, issued by another kernel -- and the bf16
+        # rounding of the branch costs accuracy (flow max-abs 0.035 -> 0.041 px).  Default: off (fp32 accumulator straight
+        # into the stream).
+        self.defer_residual = False
         self.fused_tail = True  # ufm_dpt_tail_fused where the head has the UFM-Base tail shape (bit-identical to the unfused path)
         # DPT heads on separate HIP streams: None = automatic (yes for a single-stream forward -- one pair: 9.84 -> 8.97 ms
         # graph replay, the small-grid layers of one head fill the other's tails -- no inside a micro-batch worker, where the
