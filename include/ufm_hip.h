@@ -93,6 +93,32 @@ int ufm_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M,
                   int res_row_mod, void* out, int out_dtype, int ldo, int out_row_group,
                   void* stream);
 
+/* ufm_gemm_bf16 with RoPE-2D fused into the epilogue ("fused QKV+RoPE"): columns [0, rope_cols) of the bf16 output -- the q and k
+ * heads of a QKV / Q / K|V projection of the cross-attention info-sharing variant ([U] custom_positional_encoding = CroCo RoPE2D,
+ * call site models/ufm.py:193) -- are rotated per 64-wide head on the fp32 accumulator, after bias and gamma and before the bf16
+ * rounding:  out[j] = v[j] cos[t][j] + v[j ^ 16] sin[t][j],  t = row % rope_mod, tables fp32 [rope_mod][64] (sin carries the sign;
+ * built by the host from the token grid, see ufm_rope2d).  Needs out_dtype UFM_BF16, no residual / activation / row re-mapping. */
+int ufm_gemm_bf16_rope(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, int N, int K,
+                       const float* bias, int act, const float* gamma, const float* res, int ldres,
+                       int res_row_mod, void* out, int out_dtype, int ldo, int out_row_group,
+                       const float* rope_cos, const float* rope_sin, int rope_mod, int rope_cols, void* stream);
+/* The standalone, in-place form for every activation format (numerics "parity": UFM_F32, "precise": UFM_BF16X2 with the lo plane
+ * at rows*ld elements; UFM_BF16: the reference point of the fused form): columns [col0, col0 + ncols) of x[rows][ld]. */
+int ufm_rope2d(void* x, int dtype, int rows, int ld, int col0, int ncols, const float* cos_table, const float* sin_table,
+               int mod, void* stream);
+
+/* Two-source attention (cross-attention): softmax(scale * q k^T) v with queries from one buffer and keys / values from
+ * another ([U] CrossAttention of the cross-attention info-sharing variant; also self-attention on any column layout).
+ *   q: [B*Nq][ldq], k / v: [B*Nk][ldkv], out: [B*Nq][ldo]; head h = columns [64 h, 64 h + 64) of each pointer; Nq != Nk allowed.
+ * _bf16: bf16 operands (fast), _f32: exact-fp32 MFMA (parity), _bf16x3: UFM_BF16X2 planes (precise; the lo planes follow at
+ * B*Nq*ldq, B*Nk*ldkv and B*Nq*ldo elements). */
+int ufm_cross_attention_bf16(const uint16_t* q, int ldq, const uint16_t* k, const uint16_t* v, int ldkv, uint16_t* out, int ldo,
+                             int B, int Nq, int Nk, int H, float scale, void* stream);
+int ufm_cross_attention_f32(const float* q, int ldq, const float* k, const float* v, int ldkv, float* out, int ldo, int B,
+                            int Nq, int Nk, int H, float scale, void* stream);
+int ufm_cross_attention_bf16x3(const uint16_t* q, int ldq, const uint16_t* k, const uint16_t* v, int ldkv, uint16_t* out, int ldo,
+                               int B, int Nq, int Nk, int H, float scale, void* stream);
+
 /* Tuning hooks (tests / tools only; the product path never calls them).
  * variant: 0 = auto (cost model per shape), 1 = 128x128 kernel, 4 = 256x256 8-phase kernel, 5 = hybrid (8-phase on the rows
  * that fill whole rounds of the chip + 128x128 on the rest).  flags (timing diagnostics, results are wrong): 2 = no DMA,

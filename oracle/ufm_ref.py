@@ -294,10 +294,13 @@ class UNetRef(nn.Module):
 
 def _make_head(head_type: str, feature_head_kwargs: Dict[str, Any], adaptors_kwargs: Dict[str, Any]) -> nn.Module:
     """ufm.py:243-289."""
-    assert head_type == "dpt", "oracle restates the dpt head only"
-    feat = nn.Sequential(
-        U.DPTFeature(**feature_head_kwargs["dpt_feature"]), U.DPTRegressionProcessor(**feature_head_kwargs["dpt_processor"])
-    )
+    if head_type == "moge_conv":  # ufm.py:266-267
+        feat = U.MoGeConvFeature(**feature_head_kwargs)
+    else:
+        assert head_type == "dpt", f"head_type {head_type!r} not supported"
+        feat = nn.Sequential(
+            U.DPTFeature(**feature_head_kwargs["dpt_feature"]), U.DPTRegressionProcessor(**feature_head_kwargs["dpt_processor"])
+        )
     adaptors = [_ADAPTORS[cfg["class"]](**cfg["kwargs"]) for cfg in adaptors_kwargs.values()]
     return nn.Sequential(feat, U.AdaptorMap(*adaptors))
 
@@ -548,6 +551,7 @@ def init_weights_(model: nn.Module, seed: int = 0) -> nn.Module:
 
     g = torch.Generator().manual_seed(seed)
     convt = re.compile(r"act_(1|2)_postprocess\.1\.weight$")
+    group_norm_weights = {f"{mn}.weight" for mn, m in model.named_modules() if isinstance(m, nn.GroupNorm)}  # (moge_conv head)
     with torch.no_grad():
         # named_parameters() de-duplicates the DPT act_N_postprocess / act_postprocess[N] aliases
         for name, p in sorted(model.named_parameters(), key=lambda kv: kv[0]):
@@ -556,7 +560,7 @@ def init_weights_(model: nn.Module, seed: int = 0) -> nn.Module:
                 p.copy_(torch.randn(p.shape, generator=g) * (1.0 / fan_in**0.5))
             elif name.endswith("gamma"):
                 p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
-            elif "norm" in name and name.endswith("weight"):
+            elif ("norm" in name and name.endswith("weight")) or name in group_norm_weights:
                 p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
             elif name.endswith("classification_bias"):
                 p.copy_(0.1 * torch.randn(p.shape, generator=g))

@@ -133,8 +133,46 @@ class Covariance2DAdaptorOutput:
 # --------------------------------------------------------------------------- #
 
 
+class RoPE2D(nn.Module):
+    """CroCo-style 2-D rotary embedding ([UPSTREAM-RECALL] croco/models/pos_embed.py RoPE2D, the `custom_positional_encoding`
+    of the cross-attention info-sharing variant): the head dim is split in two halves, the first rotated by the token's
+    y index and the second by its x index; inside a half of width D2 the pairs are (i, i + D2/2) with
+    theta_i = pos / freq^(2 i / D2)   (rotate_half form: out = t * cos + rotate_half(t) * sin).  Parity unpinned."""
+
+    def __init__(self, freq: float = 100.0):
+        super().__init__()
+        self.base = float(freq)
+
+    def tables(self, d2: int, positions_1d: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        inv_freq = 1.0 / (self.base ** (torch.arange(0, d2, 2, dtype=torch.float64) / d2))
+        f = positions_1d.double().unsqueeze(-1) * inv_freq  # (..., d2/2)
+        f = torch.cat((f, f), dim=-1)
+        return f.cos().float(), f.sin().float()
+
+    @staticmethod
+    def rotate_half(x: torch.Tensor) -> torch.Tensor:
+        x1, x2 = x[..., : x.shape[-1] // 2], x[..., x.shape[-1] // 2 :]
+        return torch.cat((-x2, x1), dim=-1)
+
+    def forward(self, tokens: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
+        """tokens (B, H, N, D); positions (B, N, 2) integer (y, x)."""
+        d2 = tokens.shape[-1] // 2
+        out = []
+        for half, axis in ((tokens[..., :d2], 0), (tokens[..., d2:], 1)):
+            cos, sin = self.tables(d2, positions[..., axis])  # (B, N, d2)
+            cos, sin = cos[:, None].to(tokens.dtype), sin[:, None].to(tokens.dtype)
+            out.append(half * cos + self.rotate_half(half) * sin)
+        return torch.cat(out, dim=-1)
+
+
+def grid_positions(b: int, h: int, w: int) -> torch.Tensor:
+    """(B, h*w, 2) integer (y, x) of every token of a row-major h x w grid ([UPSTREAM-RECALL] PositionGetter)."""
+    ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+    return torch.stack((ys, xs), dim=-1).reshape(1, h * w, 2).expand(b, -1, -1)
+
+
 class Attention(nn.Module):
-    def __init__(self, dim: int, num_heads: int, qkv_bias: bool = True, proj_bias: bool = True):
+    def __init__(self, dim: int, num_heads: int, qkv_bias: bool = True, proj_bias: bool = True, rope: Optional[nn.Module] = None):
         super().__init__()
         assert dim % num_heads == 0
         self.num_heads = num_heads
@@ -142,11 +180,14 @@ class Attention(nn.Module):
         self.scale = self.head_dim**-0.5
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
         self.proj = nn.Linear(dim, dim, bias=proj_bias)
+        self.rope = rope
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, xpos: Optional[torch.Tensor] = None) -> torch.Tensor:
         b, n, c = x.shape
         qkv = self.qkv(x).reshape(b, n, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0], qkv[1], qkv[2]
+        if self.rope is not None:
+            q, k = self.rope(q, xpos), self.rope(k, xpos)
         # explicit softmax(q k^T * scale) v ; kept explicit (not SDPA) so the
         # oracle has no dependence on a fused kernel's internal choices.
         if n <= 4096:
@@ -455,6 +496,132 @@ class MultiViewGlobalAttentionTransformerIFR(nn.Module):
         return final, inter
 
 
+# --------------------------------------------------------------------------- #
+# multi-view cross-attention transformer ("cross_attention"): CroCo / DUSt3R decoder
+# layout -- one branch of blocks per view; every block = self-attention, cross-attention
+# to the OTHER views' tokens of the previous layer, MLP.  [UPSTREAM-RECALL]; parity unpinned.
+# --------------------------------------------------------------------------- #
+
+
+class CrossAttention(nn.Module):
+    def __init__(self, dim: int, num_heads: int, qkv_bias: bool = True, rope: Optional[nn.Module] = None):
+        super().__init__()
+        self.num_heads = num_heads
+        self.head_dim = dim // num_heads
+        self.scale = self.head_dim**-0.5
+        self.projq = nn.Linear(dim, dim, bias=qkv_bias)
+        self.projk = nn.Linear(dim, dim, bias=qkv_bias)
+        self.projv = nn.Linear(dim, dim, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        self.rope = rope
+
+    def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, qpos=None, kpos=None) -> torch.Tensor:
+        b, nq, c = query.shape
+        nk = key.shape[1]
+        q = self.projq(query).reshape(b, nq, self.num_heads, self.head_dim).permute(0, 2, 1, 3)
+        k = self.projk(key).reshape(b, nk, self.num_heads, self.head_dim).permute(0, 2, 1, 3)
+        v = self.projv(value).reshape(b, nk, self.num_heads, self.head_dim).permute(0, 2, 1, 3)
+        if self.rope is not None:
+            q, k = self.rope(q, qpos), self.rope(k, kpos)
+        attn = ((q * self.scale) @ k.transpose(-2, -1)).softmax(dim=-1)
+        return self.proj((attn @ v).transpose(1, 2).reshape(b, nq, c))
+
+
+class CrossAttentionBlock(nn.Module):
+    """x += ls1(attn(norm1 x)); x += ls2(cross_attn(norm2 x, norm_y y, norm_y y)); x += ls3(mlp(norm3 x))"""
+
+    def __init__(self, dim: int, num_heads: int, mlp_ratio: float = 4.0, qkv_bias: bool = True, init_values: Optional[float] = None,
+                 norm_cross_tokens: bool = True, rope: Optional[nn.Module] = None, eps: float = 1e-6):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=eps)
+        self.attn = Attention(dim, num_heads, qkv_bias=qkv_bias, rope=rope)
+        self.ls1 = LayerScale(dim, init_values) if init_values is not None else nn.Identity()
+        self.norm_y = nn.LayerNorm(dim, eps=eps) if norm_cross_tokens else nn.Identity()
+        self.norm2 = nn.LayerNorm(dim, eps=eps)
+        self.cross_attn = CrossAttention(dim, num_heads, qkv_bias=qkv_bias, rope=rope)
+        self.ls2 = LayerScale(dim, init_values) if init_values is not None else nn.Identity()
+        self.norm3 = nn.LayerNorm(dim, eps=eps)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+        self.ls3 = LayerScale(dim, init_values) if init_values is not None else nn.Identity()
+
+    def forward(self, x: torch.Tensor, y: torch.Tensor, xpos=None, ypos=None) -> torch.Tensor:
+        x = x + self.ls1(self.attn(self.norm1(x), xpos))
+        y_ = self.norm_y(y)
+        x = x + self.ls2(self.cross_attn(self.norm2(x), y_, y_, xpos, ypos))
+        x = x + self.ls3(self.mlp(self.norm3(x)))
+        return x
+
+
+class MultiViewCrossAttentionTransformerIFR(nn.Module):
+    """``INFO_SHARING_CLASSES["cross_attention"][1]``.  Every view has its own branch of ``depth`` blocks; at layer l each
+    view's tokens attend to themselves and to the concatenated layer-(l-1) tokens of all OTHER views (both views are
+    updated from the previous layer's outputs, as in DUSt3R's two decoders).  ``rope_freq``: enable the CroCo RoPE-2D on
+    q / k of both attentions (upstream passes a callable `custom_positional_encoding`, which a JSON config cannot hold).
+    Same IO contract as the global-attention variant (ufm.py:598-615)."""
+
+    def __init__(
+        self,
+        name: str = "cross_attention",
+        input_embed_dim: int = 1024,
+        num_views: int = 2,
+        size: Optional[str] = None,
+        depth: int = 12,
+        dim: int = 768,
+        num_heads: int = 12,
+        mlp_ratio: float = 4.0,
+        qkv_bias: bool = True,
+        init_values: Optional[float] = None,
+        indices: Optional[List[int]] = None,
+        norm_intermediate: bool = True,
+        norm_cross_tokens: bool = True,
+        rope_freq: Optional[float] = None,
+        **_: Any,
+    ):
+        super().__init__()
+        if size is not None:
+            depth, dim, num_heads = {"base": (12, 768, 12), "large": (24, 1024, 16)}[size]
+        self.name, self.input_embed_dim, self.num_views = name, input_embed_dim, num_views
+        self.depth, self.dim, self.num_heads = depth, dim, num_heads
+        self.proj_embed = nn.Linear(input_embed_dim, dim, bias=True) if input_embed_dim != dim else nn.Identity()
+        self.rope = RoPE2D(rope_freq) if rope_freq else None
+        self.multi_view_branches = nn.ModuleList(
+            [
+                nn.ModuleList([CrossAttentionBlock(dim, num_heads, mlp_ratio, qkv_bias, init_values, norm_cross_tokens, self.rope) for _ in range(depth)])
+                for _ in range(num_views)
+            ]
+        )
+        self.norm = nn.LayerNorm(dim, eps=1e-6)
+        if indices is None:
+            indices = [depth // 2 - 1, (3 * depth) // 4 - 1]
+        self.indices = list(indices)
+        self.norm_intermediate = norm_intermediate
+
+    def forward(self, model_input: MultiViewTransformerInput):
+        feats = model_input.features
+        v = len(feats)
+        assert v == self.num_views
+        b, c, h, w = feats[0].shape
+        assert all(f.shape == feats[0].shape for f in feats) and c == self.input_embed_dim
+        xs = [self.proj_embed(f.permute(0, 2, 3, 1).reshape(b, h * w, c)) for f in feats]
+        pos = grid_positions(b, h, w) if self.rope is not None else None
+        opos = torch.cat([pos] * (v - 1), dim=1) if pos is not None else None
+
+        def to_maps(tokens):
+            return [t.reshape(b, h, w, self.dim).permute(0, 3, 1, 2).contiguous() for t in tokens]
+
+        inter: List[MultiViewTransformerOutput] = []
+        for layer in range(self.depth):
+            prev = xs
+            xs = [
+                self.multi_view_branches[i][layer](prev[i], torch.cat([prev[j] for j in range(v) if j != i], dim=1), pos, opos)
+                for i in range(v)
+            ]
+            if layer in self.indices:
+                inter.append(MultiViewTransformerOutput(features=to_maps([self.norm(t) if self.norm_intermediate else t for t in xs])))
+        final = MultiViewTransformerOutput(features=to_maps([self.norm(t) for t in xs]))
+        return final, inter
+
+
 class _NoIFRVariant(nn.Module):
     def __init__(self, *a: Any, **k: Any):
         raise NotImplementedError("only the intermediate-feature-returner variant is on the UFM path (ufm.py:193)")
@@ -462,6 +629,7 @@ class _NoIFRVariant(nn.Module):
 
 INFO_SHARING_CLASSES = {
     "global_attention": (_NoIFRVariant, MultiViewGlobalAttentionTransformerIFR),
+    "cross_attention": (_NoIFRVariant, MultiViewCrossAttentionTransformerIFR),
 }
 
 
@@ -586,10 +754,104 @@ class MLPFeature(nn.Module):
         return PixelTaskOutput(decoded_channels=x)
 
 
-class MoGeConvFeature(nn.Module):
-    def __init__(self, *a: Any, **k: Any):
+def normalized_view_plane_uv(width: int, height: int, aspect_ratio: float) -> torch.Tensor:
+    """(H, W, 2) view-plane coordinates of pixel centres, the image diagonal spanning [-1, 1]^2-ish
+    ([UPSTREAM-RECALL] MoGe utils.geometry_torch.normalized_view_plane_uv): u along x, v along y."""
+    span_x = aspect_ratio / (1 + aspect_ratio**2) ** 0.5
+    span_y = 1 / (1 + aspect_ratio**2) ** 0.5
+    u = torch.linspace(-span_x * (width - 1) / width, span_x * (width - 1) / width, width, dtype=torch.float32)
+    v = torch.linspace(-span_y * (height - 1) / height, span_y * (height - 1) / height, height, dtype=torch.float32)
+    u, v = torch.meshgrid(u, v, indexing="xy")
+    return torch.stack([u, v], dim=-1)
+
+
+class ResidualConvBlock(nn.Module):
+    """GroupNorm -> ReLU -> conv3x3 (replicate padding) -> GroupNorm -> ReLU -> conv3x3 (replicate) + skip
+    ([UPSTREAM-RECALL] MoGe ResidualConvBlock; 'group_norm' = 32 channels per group, 'layer_norm' = one group)."""
+
+    def __init__(self, in_channels: int, out_channels: Optional[int] = None, hidden_channels: Optional[int] = None, norm: str = "group_norm"):
         super().__init__()
-        raise NotImplementedError("moge_conv head is outside the UFM-Base/Refine hot path (SURVEY 8(f) rank 4)")
+        out_channels = out_channels or in_channels
+        hidden_channels = hidden_channels or in_channels
+        groups = (lambda ch: max(ch // 32, 1)) if norm == "group_norm" else (lambda ch: 1)
+        self.layers = nn.Sequential(
+            nn.GroupNorm(groups(in_channels), in_channels),
+            nn.ReLU(),
+            nn.Conv2d(in_channels, hidden_channels, 3, padding=1, padding_mode="replicate"),
+            nn.GroupNorm(groups(hidden_channels), hidden_channels),
+            nn.ReLU(),
+            nn.Conv2d(hidden_channels, out_channels, 3, padding=1, padding_mode="replicate"),
+        )
+        self.skip_connection = nn.Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else nn.Identity()
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.layers(x) + self.skip_connection(x)
+
+
+class MoGeConvFeature(nn.Module):
+    """``head_type="moge_conv"`` (ufm.py:266-267): the convolutional head of MoGe ([UPSTREAM-RECALL] MoGe v1 `Head`,
+    wrapped by uniception as MoGeConvFeature).  Per-level 1x1 projections summed at the token grid; three x2 stages
+    {concat view-plane uv, ConvTranspose2d(k=s=2), conv3x3 replicate, residual conv blocks}; bilinear
+    (align_corners=False) to the target shape; concat uv; per-output block conv3x3 -> ReLU -> conv.  Parity unpinned."""
+
+    def __init__(
+        self,
+        input_feature_dims: Union[int, Sequence[int]] = 768,
+        dim_out: Union[int, Sequence[int]] = 2,
+        num_features: int = 4,
+        dim_proj: int = 512,
+        dim_upsample: Sequence[int] = (256, 128, 128),
+        dim_times_res_block_hidden: int = 1,
+        num_res_blocks: int = 1,
+        res_block_norm: str = "group_norm",
+        last_res_blocks: int = 0,
+        last_conv_channels: int = 32,
+        last_conv_size: int = 1,
+        patch_size: int = 14,
+        **_: Any,
+    ):
+        super().__init__()
+        if isinstance(input_feature_dims, int):
+            input_feature_dims = [input_feature_dims] * num_features
+        if isinstance(dim_out, int):
+            dim_out = [dim_out]
+        assert len(input_feature_dims) == num_features
+        self.patch_size = patch_size
+        self.dim_out = list(dim_out)
+        self.projects = nn.ModuleList([nn.Conv2d(c, dim_proj, 1) for c in input_feature_dims])
+        dims_in = [dim_proj] + list(dim_upsample[:-1])
+        self.upsample_blocks = nn.ModuleList(
+            [
+                nn.Sequential(
+                    nn.Sequential(nn.ConvTranspose2d(cin + 2, cout, 2, 2), nn.Conv2d(cout, cout, 3, 1, 1, padding_mode="replicate")),
+                    *[ResidualConvBlock(cout, cout, dim_times_res_block_hidden * cout, res_block_norm) for _ in range(num_res_blocks)],
+                )
+                for cin, cout in zip(dims_in, dim_upsample)
+            ]
+        )
+        self.output_block = nn.ModuleList(
+            [
+                nn.Sequential(
+                    nn.Conv2d(dim_upsample[-1] + 2, last_conv_channels, 3, 1, 1, padding_mode="replicate"),
+                    *[ResidualConvBlock(last_conv_channels, last_conv_channels, dim_times_res_block_hidden * last_conv_channels, res_block_norm) for _ in range(last_res_blocks)],
+                    nn.ReLU(inplace=True),
+                    nn.Conv2d(last_conv_channels, d, last_conv_size, 1, last_conv_size // 2, padding_mode="replicate"),
+                )
+                for d in self.dim_out
+            ]
+        )
+
+    def forward(self, head_input: PredictionHeadLayeredInput) -> PixelTaskOutput:
+        img_h, img_w = head_input.target_output_shape
+        x = torch.stack([proj(f) for proj, f in zip(self.projects, head_input.list_features)], dim=1).sum(dim=1)
+        for block in self.upsample_blocks:
+            uv = normalized_view_plane_uv(x.shape[-1], x.shape[-2], img_w / img_h).to(x)
+            x = torch.cat([x, uv.permute(2, 0, 1).unsqueeze(0).expand(x.shape[0], -1, -1, -1)], dim=1)
+            x = block(x)
+        x = F.interpolate(x, (img_h, img_w), mode="bilinear", align_corners=False)
+        uv = normalized_view_plane_uv(img_w, img_h, img_w / img_h).to(x)
+        x = torch.cat([x, uv.permute(2, 0, 1).unsqueeze(0).expand(x.shape[0], -1, -1, -1)], dim=1)
+        return PixelTaskOutput(decoded_channels=torch.cat([blk(x) for blk in self.output_block], dim=1))
 
 
 # --------------------------------------------------------------------------- #

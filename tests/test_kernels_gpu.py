@@ -647,6 +647,113 @@ def test_conv2d_bf16x3(hip, B, H, W, Cin, Cout, k, stride, pad, relu_in, act, nr
     assert err <= 4e-5 * max(1.0, ref.abs().max().item()), err
 
 
+# ---- the cross-attention info-sharing variant's kernels: two-source attention, RoPE-2D (standalone and fused into the GEMM) ----
+def cross_attn_ref(q, k, v, B, Nq, Nk, H, scale):
+    qh = q.double().reshape(B, Nq, H, 64).permute(0, 2, 1, 3)
+    kh = k.double().reshape(B, Nk, H, 64).permute(0, 2, 1, 3)
+    vh = v.double().reshape(B, Nk, H, 64).permute(0, 2, 1, 3)
+    p = torch.softmax((qh @ kh.transpose(-1, -2)) * scale, dim=-1)
+    return (p @ vh).permute(0, 2, 1, 3).reshape(B * Nq, H * 64)
+
+
+@pytest.mark.parametrize("B,Nq,Nk,H", [(1, 17, 40, 1), (2, 100, 37, 2), (2, 300, 1369, 2), (1, 1369, 130, 3), (3, 64, 64, 1)])
+@pytest.mark.parametrize("fmt", ["bf16", "f32", "x3"])
+def test_cross_attention_two_sources(hip, B, Nq, Nk, H, fmt):
+    """ufm_cross_attention_*: queries [B*Nq][ldq] against keys / values of ANOTHER buffer [B*Nk][ldkv], Nq != Nk, K and V as
+    column blocks of one K|V projection output (ldkv = 2 H 64), Q inside a wider buffer (ldq > H 64)."""
+    D = H * 64
+    qbuf = rnd(B * Nq, D + 64, seed=Nq, scale=1.5)       # queries in columns [0, D) of a wider buffer
+    kv = rnd(B * Nk, 2 * D, seed=Nk + 1, scale=1.5)
+    if fmt == "bf16":
+        qbuf, kv = bf16r(qbuf), bf16r(kv)
+    elif fmt == "x3":
+        qs, kvs = split(qbuf), split(kv)
+        qbuf, kv = unsplit(qs), unsplit(kvs)
+    ref = cross_attn_ref(qbuf[:, :D], kv[:, :D], kv[:, D:], B, Nq, Nk, H, 0.125)
+    if fmt == "x3":
+        qd, kvd = qs.to(DEV), kvs.to(DEV)
+        out = torch.zeros(2, B * Nq, D, device=DEV, dtype=torch.bfloat16)
+        hip.cross_attention(qd[0][:, :D], D + 64, kvd[0][:, :D], kvd[0][:, D:], 2 * D, out[0], D, B, Nq, Nk, H, 0.125, hip.BF16X2)
+        got, tol = unsplit(out.cpu()).double(), 1e-4
+    else:
+        dt = torch.bfloat16 if fmt == "bf16" else torch.float32
+        qd, kvd = qbuf.to(DEV).to(dt), kv.to(DEV).to(dt)
+        out = torch.zeros(B * Nq, D, device=DEV, dtype=dt)
+        hip.cross_attention(qd[:, :D], D + 64, kvd[:, :D], kvd[:, D:], 2 * D, out, D, B, Nq, Nk, H, 0.125, hip.BF16 if fmt == "bf16" else hip.F32)
+        got, tol = out.float().cpu().double(), (2e-2 if fmt == "bf16" else 2e-5)
+    err = (got - ref).abs().max().item()
+    assert err <= tol, err
+
+
+def rope_ref(x, gh, gw, H, freq=100.0):
+    """The oracle's CroCo RoPE2D on a (rows = B*gh*gw, H*64) projection output."""
+    from oracle.uniception_ref import RoPE2D, grid_positions
+
+    Np = gh * gw
+    B = x.shape[0] // Np
+    t = x.reshape(B, Np, H, 64).permute(0, 2, 1, 3)
+    return RoPE2D(freq)(t, grid_positions(B, gh, gw)).permute(0, 2, 1, 3).reshape(B * Np, H * 64)
+
+
+def rope_tables(gh, gw, freq=100.0):
+    """Host tables as the engine builds them, via the engine's own routine on a stub."""
+    import types
+
+    from ufm_amd.engine import Engine
+
+    stub = types.SimpleNamespace(_tables={}, rope_freq=freq, dev=torch.device(DEV))
+    return Engine._rope_tables(stub, gh, gw)
+
+
+@pytest.mark.parametrize("fmt", ["f32", "bf16", "x3"])
+def test_rope2d_standalone_matches_the_oracle(hip, fmt):
+    gh, gw, H, B = 5, 7, 3, 2
+    Np, D = gh * gw, H * 64
+    x = rnd(B * Np, 3 * D, seed=7)                      # a QKV buffer: rotate q and k (columns [0, 2D)), leave v alone
+    cos, sin = rope_tables(gh, gw)
+    if fmt == "bf16":
+        x = bf16r(x)
+    if fmt == "x3":
+        xs = split(x)
+        x = unsplit(xs)
+        buf = xs.to(DEV)
+    else:
+        buf = x.to(DEV).to(torch.bfloat16 if fmt == "bf16" else torch.float32)
+    want = torch.cat([rope_ref(x[:, :D], gh, gw, H), rope_ref(x[:, D : 2 * D], gh, gw, H), x[:, 2 * D :]], dim=1)
+    hip.rope2d(buf, B * Np, 3 * D, 0, 2 * D, cos, sin, Np)
+    got = unsplit(buf.cpu()) if fmt == "x3" else buf.float().cpu()
+    err = (got - want).abs().max().item()
+    assert err <= (3e-2 if fmt == "bf16" else 2e-5 if fmt == "x3" else 2e-6), err
+    assert torch.equal(got[:, 2 * D :], x[:, 2 * D :]) or fmt == "x3"  # the v columns are untouched
+
+
+@pytest.mark.parametrize("M_mult,N,K,rope_cols", [(3, 384, 128, 256), (40, 3072, 1024, 2048), (9, 256, 192, 256)])
+def test_gemm_fused_rope_matches_linear_then_rope(hip, M_mult, N, K, rope_cols):
+    """ufm_gemm_bf16_rope ("fused QKV+RoPE"): the rotation runs on the fp32 accumulator (+ bias, x gamma) before the bf16
+    rounding; against fp64 Linear -> oracle RoPE2D, on the 128x128 and the 8-phase kernels, with a ragged last row tile."""
+    gh, gw = 5, 7
+    Np = gh * gw
+    M = M_mult * Np
+    A = bf16r(rnd(M, K, seed=1))
+    W = bf16r(rnd(N, K, seed=2, scale=K**-0.5))
+    bias, gamma = rnd(N, seed=3, scale=0.1), 1 + rnd(N, seed=4, scale=0.1)
+    lin = ((A.double() @ W.double().T + bias.double()) * gamma.double()).float()
+    H = rope_cols // 64
+    want = torch.cat([rope_ref(lin[:, :rope_cols], gh, gw, H), lin[:, rope_cols:]], dim=1).double()
+    cos, sin = rope_tables(gh, gw)
+    out = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    hip.gemm_bf16(A.to(DEV).bfloat16(), W.to(DEV).bfloat16(), M, N, K, out, bias=bias.to(DEV), gamma=gamma.to(DEV), rope=(cos, sin, Np, rope_cols))
+    err = (out.float().cpu().double() - want).abs().max().item()
+    assert err <= 2e-2 * max(1.0, want.abs().max().item()), err
+    # and the un-rotated columns are bitwise those of the plain GEMM
+    plain = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    hip.gemm_bf16(A.to(DEV).bfloat16(), W.to(DEV).bfloat16(), M, N, K, plain, bias=bias.to(DEV), gamma=gamma.to(DEV))
+    if rope_cols < N:
+        assert torch.equal(out[:, rope_cols:], plain[:, rope_cols:])
+    with pytest.raises(RuntimeError, match="plain bf16 output"):
+        hip.gemm_bf16(A.to(DEV).bfloat16(), W.to(DEV).bfloat16(), M, N, K, torch.zeros(M, N, device=DEV), rope=(cos, sin, Np, rope_cols))
+
+
 # ---- numerics "precise": the transformer's Linear layers and attention on the split format ----
 @pytest.mark.parametrize(
     "M,N,K,act,use_gamma,use_res,split_out",

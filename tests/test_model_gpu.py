@@ -156,6 +156,37 @@ def test_fast_mode_deferred_residual_update_matches_the_in_epilogue_form(env):
     assert (ma - b.covisibility.mask).abs().max().item() <= 0.01
 
 
+@pytest.mark.parametrize("rope_freq", [None, 100.0])
+@pytest.mark.parametrize("refine", [False, True])
+def test_cross_attention_info_sharing_vs_oracle(env, rope_freq, refine):
+    """info_sharing_str="cross_attention" (ufm.py:193) -- per-view branches of {self-attention,
+    cross-attention to the other view's previous-layer tokens, MLP} blocks, optional RoPE-2D on q / k (fused into the QKV /
+    Q / K|V GEMM epilogues in "fast") -- against the oracle's restatement (PARITY UNPINNED: the uniception class is absent
+    from the reference) in all three numerics, through the real two-source attention kernels."""
+    ufm_amd, R = env
+
+    def cfg(mod):
+        c = mod.ufm_tiny_config(refine=refine)
+        c["info_sharing_str"] = "cross_attention"
+        c["info_sharing_kwargs"] = dict(name="info_sharing", input_embed_dim=128, num_views=2, depth=4, dim=128, num_heads=2, rope_freq=rope_freq, init_values=1.0)
+        return c
+
+    oracle, prod = build_pair(env, refine=refine, cfg_fn=cfg)
+    src, tgt = u8((3, 56, 56, 3), 21), u8((3, 56, 56, 3), 22)
+    o = oracle.predict_correspondences_batched(src, tgt)
+    for mode in ("parity", "precise"):
+        p = prod.set_numerics(mode).predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
+        df, dm, mx = compare(o, p)
+        assert df <= 1e-3 and dm <= 1e-3, (mode, df, dm, mx)
+    p = prod.set_numerics("fast").predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
+    df, dm, mx = compare(o, p)
+    print(f"cross_attention (rope={rope_freq}, refine={refine}) fast: flow max-abs {df:.3g} (range {mx:.3g}), mask {dm:.3g}")
+    assert df <= 0.02 * mx and dm <= 0.02, (df, dm, mx)
+    # view order matters in this variant (each view has its own branch): swapping the inputs is a different computation
+    q = prod.set_numerics("parity").predict_correspondences_batched(tgt.to(DEV), src.to(DEV))
+    assert (q.flow.flow_output - prod.predict_correspondences_batched(src.to(DEV), tgt.to(DEV)).flow.flow_output).abs().max().item() > 1e-3
+
+
 def test_forward_lower_level_api_and_errors(env):
     ufm_amd, R = env
     oracle, prod = build_pair(env)

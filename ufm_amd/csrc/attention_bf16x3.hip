@@ -30,27 +30,30 @@ __device__ __forceinline__ bf16x4 tr_read(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_ptr)LDS_PTR(p));
 }
 
-__global__ __launch_bounds__(256, 2) void attn_x3_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
-                                                         long long in_plane, long long out_plane, int N, int H, float c) {
+// Two-source form (as attention_bf16.hip): Q [2][B*Nq][ldq] (lo plane at +q_plane), K / V [2][B*N][ldkv] (+kv_plane),
+// out [2][B*Nq][ldo] (+out_plane).
+__global__ __launch_bounds__(256, 2) void attn_x3_kernel(const uint16_t* __restrict__ qp_, int ldq, long long q_plane,
+                                                         const uint16_t* __restrict__ kp_, const uint16_t* __restrict__ vp_, int ldkv, long long in_plane,
+                                                         uint16_t* __restrict__ out, int ldo, long long out_plane, int Nq, int N, int H, float c) {
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nqb = (N + QB - 1) / QB;
+    const int nqb = (Nq + QB - 1) / QB;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);  // all query blocks of one (image, head) share an XCD's L2
     const int qblk = lid % nqb, head = (lid / nqb) % H, b = lid / (nqb * H);
-    const int ld = 3 * H * 64;
-    const uint16_t* base = qkv + (size_t)b * N * ld + head * 64;
-    const uint16_t* kp = base + H * 64;
-    const uint16_t* vp = base + 2 * H * 64;
+    const int ld = ldkv;
+    const uint16_t* base = qp_ + (size_t)b * Nq * ldq + head * 64;
+    const uint16_t* kp = kp_ + (size_t)b * N * ldkv + head * 64;
+    const uint16_t* vp = vp_ + (size_t)b * N * ldkv + head * 64;
     const int ql = lane & 31, hh = lane >> 5;
     const int q = qblk * QB + wave * 32 + ql;
 
     bf16x8 qh[4], qlo[4];
     {
-        const uint16_t* qr = base + (size_t)min(q, N - 1) * ld + 8 * hh;
+        const uint16_t* qr = base + (size_t)min(q, Nq - 1) * ldq + 8 * hh;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             qh[s] = *(const bf16x8*)(qr + 16 * s);
-            qlo[s] = *(const bf16x8*)(qr + in_plane + 16 * s);
+            qlo[s] = *(const bf16x8*)(qr + q_plane + 16 * s);
         }
     }
 
@@ -218,8 +221,8 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(const uint16_t* __restr
     // ---- epilogue: O[q][d] = O^T[d][q] / l, stored as (hi, lo) planes ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
-    if (q < N) {
-        uint16_t* orow = out + ((size_t)b * N + q) * (H * 64) + head * 64 + 4 * hh;
+    if (q < Nq) {
+        uint16_t* orow = out + ((size_t)b * Nq + q) * ldo + head * 64 + 4 * hh;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -247,8 +250,21 @@ extern "C" int ufm_attention_bf16x3(const uint16_t* qkv, uint16_t* out, int B, i
     UFM_REQUIRE(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 8) == 0, "ufm_attention_bf16x3: misaligned pointer");
     const long long rows = (long long)B * N;
     dim3 grid(((N + QB - 1) / QB) * H * B), block(256);
-    hipLaunchKernelGGL(attn_x3_kernel, grid, block, 0, (hipStream_t)stream, qkv, out, rows * 3 * H * 64, rows * H * 64, N, H,
-                       scale * 1.44269504088896340736f);
+    hipLaunchKernelGGL(attn_x3_kernel, grid, block, 0, (hipStream_t)stream, qkv, 3 * H * 64, rows * 3 * H * 64, qkv + H * 64, qkv + 2 * H * 64, 3 * H * 64,
+                       rows * 3 * H * 64, out, H * 64, rows * H * 64, N, N, H, scale * 1.44269504088896340736f);
     UFM_CHECK_LAUNCH("ufm_attention_bf16x3");
+    return UFM_OK;
+}
+
+extern "C" int ufm_cross_attention_bf16x3(const uint16_t* q, int ldq, const uint16_t* k, const uint16_t* v, int ldkv, uint16_t* out, int ldo,
+                                          int B, int Nq, int Nk, int H, float scale, void* stream) {
+    UFM_REQUIRE(q && k && v && out, "ufm_cross_attention_bf16x3: null pointer");
+    UFM_REQUIRE(B > 0 && Nq > 0 && Nk > 0 && H > 0 && scale > 0.0f && (int64_t)((Nq + QB - 1) / QB) * H * B < (1ll << 31), "ufm_cross_attention_bf16x3: bad shape");
+    UFM_REQUIRE(ldq >= H * 64 && ldkv >= H * 64 && ldo >= H * 64 && ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 4 == 0, "ufm_cross_attention_bf16x3: bad leading dimensions %d/%d/%d", ldq, ldkv, ldo);
+    UFM_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 && ((uintptr_t)out % 8) == 0, "ufm_cross_attention_bf16x3: misaligned pointer");
+    dim3 grid(((Nq + QB - 1) / QB) * H * B), block(256);
+    hipLaunchKernelGGL(attn_x3_kernel, grid, block, 0, (hipStream_t)stream, q, ldq, (long long)B * Nq * ldq, k, v, ldkv, (long long)B * Nk * ldkv, out, ldo,
+                       (long long)B * Nq * ldo, Nq, Nk, H, scale * 1.44269504088896340736f);
+    UFM_CHECK_LAUNCH("ufm_cross_attention_bf16x3");
     return UFM_OK;
 }

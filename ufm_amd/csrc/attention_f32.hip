@@ -12,24 +12,26 @@ namespace {
 constexpr int QB = 128, KB = 64;
 constexpr float NEG_BIG = -1.0e30f;
 
-__global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N,
-                                                       int H, float scale) {
+// Two-source form (as attention_bf16.hip): Q [B*Nq][ldq], K / V [B*N][ldkv], out [B*Nq][ldo].
+__global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__ qp_, int ldq, const float* __restrict__ kp_,
+                                                       const float* __restrict__ vp_, int ldkv, float* __restrict__ out, int ldo,
+                                                       int Nq, int N, int H, float scale) {
     __shared__ __attribute__((aligned(16))) float sK[KB * 64];
     __shared__ __attribute__((aligned(16))) float sV[KB * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nqb = (N + QB - 1) / QB;
+    const int nqb = (Nq + QB - 1) / QB;
     const int lid = blockIdx.x;
     const int qblk = lid % nqb, head = (lid / nqb) % H, b = lid / (nqb * H);
-    const int ld = 3 * H * 64;
-    const float* base = qkv + (size_t)b * N * ld + head * 64;
-    const float* kp = base + H * 64;
-    const float* vp = base + 2 * H * 64;
+    const int ld = ldkv;
+    const float* base = qp_ + (size_t)b * Nq * ldq + head * 64;
+    const float* kp = kp_ + (size_t)b * N * ldkv + head * 64;
+    const float* vp = vp_ + (size_t)b * N * ldkv + head * 64;
     const int ql = lane & 31, hh = lane >> 5;
     const int q = qblk * QB + wave * 32 + ql;
 
     f32x4 qf[8];
     {
-        const float* qr = base + (size_t)min(q, N - 1) * ld + 4 * hh;
+        const float* qr = base + (size_t)min(q, Nq - 1) * ldq + 4 * hh;
 #pragma unroll
         for (int st = 0; st < 8; ++st) qf[st] = *(const f32x4*)(qr + 8 * st);
     }
@@ -110,8 +112,8 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
-    if (q < N) {
-        float* orow = out + ((size_t)b * N + q) * (H * 64) + head * 64 + 4 * hh;
+    if (q < Nq) {
+        float* orow = out + ((size_t)b * Nq + q) * ldo + head * 64 + 4 * hh;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -129,7 +131,19 @@ extern "C" int ufm_attention_f32(const float* qkv, float* out, int B, int N, int
     UFM_REQUIRE(B > 0 && N > 0 && H > 0 && (int64_t)((N + QB - 1) / QB) * H * B < (1ll << 31), "ufm_attention_f32: bad shape");
     UFM_REQUIRE(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0, "ufm_attention_f32: misaligned pointer");
     dim3 grid(((N + QB - 1) / QB) * H * B), block(256);
-    hipLaunchKernelGGL(attn_f32_kernel, grid, block, 0, (hipStream_t)stream, qkv, out, N, H, scale);
+    hipLaunchKernelGGL(attn_f32_kernel, grid, block, 0, (hipStream_t)stream, qkv, 3 * H * 64, qkv + H * 64, qkv + 2 * H * 64, 3 * H * 64, out, H * 64, N, N, H, scale);
     UFM_CHECK_LAUNCH("ufm_attention_f32");
+    return UFM_OK;
+}
+
+extern "C" int ufm_cross_attention_f32(const float* q, int ldq, const float* k, const float* v, int ldkv, float* out, int ldo, int B,
+                                       int Nq, int Nk, int H, float scale, void* stream) {
+    UFM_REQUIRE(q && k && v && out, "ufm_cross_attention_f32: null pointer");
+    UFM_REQUIRE(B > 0 && Nq > 0 && Nk > 0 && H > 0 && scale > 0.0f && (int64_t)((Nq + QB - 1) / QB) * H * B < (1ll << 31), "ufm_cross_attention_f32: bad shape");
+    UFM_REQUIRE(ldq >= H * 64 && ldkv >= H * 64 && ldo >= H * 64 && ldq % 4 == 0 && ldkv % 4 == 0 && ldo % 4 == 0, "ufm_cross_attention_f32: bad leading dimensions %d/%d/%d", ldq, ldkv, ldo);
+    UFM_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 && ((uintptr_t)out % 16) == 0, "ufm_cross_attention_f32: misaligned pointer");
+    dim3 grid(((Nq + QB - 1) / QB) * H * B), block(256);
+    hipLaunchKernelGGL(attn_f32_kernel, grid, block, 0, (hipStream_t)stream, q, ldq, k, v, ldkv, out, ldo, Nq, Nk, H, scale);
+    UFM_CHECK_LAUNCH("ufm_cross_attention_f32");
     return UFM_OK;
 }

@@ -141,7 +141,23 @@ extern "C" int ufm_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int 
                              const float* bias, int act, const float* gamma, const float* res, int ldres,
                              int res_row_mod, void* out, int out_dtype, int ldo, int out_row_group,
                              void* stream) {
+    return ufm_gemm_bf16_rope(A, lda, W, ldw, M, N, K, bias, act, gamma, res, ldres, res_row_mod, out, out_dtype, ldo, out_row_group,
+                              nullptr, nullptr, 0, 0, stream);
+}
+
+// The same GEMM with RoPE-2D fused into the epilogue (the north star's "fused QKV+RoPE"): columns [0, rope_cols) of the bf16
+// output -- the q and k heads of a QKV / Q / KV projection -- are rotated on the fp32 accumulator (after bias and gamma,
+// before the bf16 rounding) with the tables [rope_mod][64] of rope.hip, row % rope_mod = the token's index in its image.
+extern "C" int ufm_gemm_bf16_rope(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, int N, int K,
+                                  const float* bias, int act, const float* gamma, const float* res, int ldres,
+                                  int res_row_mod, void* out, int out_dtype, int ldo, int out_row_group,
+                                  const float* rope_cos, const float* rope_sin, int rope_mod, int rope_cols, void* stream) {
     UFM_REQUIRE(A && W && out, "ufm_gemm_bf16: null pointer");
+    if (rope_cos || rope_sin) {
+        UFM_REQUIRE(rope_cos && rope_sin && rope_mod > 0 && rope_cols > 0 && rope_cols % 64 == 0 && rope_cols <= N, "ufm_gemm_bf16_rope: bad RoPE arguments (mod=%d cols=%d)", rope_mod, rope_cols);
+        UFM_REQUIRE(out_dtype == UFM_BF16 && !res && out_row_group == 0 && act == UFM_ACT_NONE && ldo % 8 == 0 && ((uintptr_t)out % 16) == 0,
+                    "ufm_gemm_bf16_rope: the fused rotation needs a plain bf16 output (no residual, activation or row re-mapping)");
+    }
     UFM_REQUIRE(M > 0 && N > 0 && K > 0, "ufm_gemm_bf16: empty problem M=%d N=%d K=%d", M, N, K);
     UFM_REQUIRE(K % BK == 0, "ufm_gemm_bf16: K=%d must be a multiple of %d", K, BK);
     UFM_REQUIRE(N % BN == 0, "ufm_gemm_bf16: N=%d must be a multiple of %d", N, BN);
@@ -150,7 +166,7 @@ extern "C" int ufm_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int 
     UFM_REQUIRE(ldo % 4 == 0 && ldo >= N && (!res || (ldres % 4 == 0 && ldres >= N)), "ufm_gemm_bf16: bad ldo/ldres");
     UFM_REQUIRE(out_dtype == UFM_F32 || out_dtype == UFM_BF16, "ufm_gemm_bf16: bad out_dtype %d", out_dtype);
     UFM_REQUIRE((size_t)M * (size_t)(lda > ldo ? lda : ldo) < (1ull << 40), "ufm_gemm_bf16: problem too large");
-    GemmArgs p{A, W, bias, gamma, res, out, lda, ldw, M, N, K, act, ldres, res_row_mod, ldo, out_row_group, g_gemm_flags, 0};
+    GemmArgs p{A, W, bias, gamma, res, out, lda, ldw, M, N, K, act, ldres, res_row_mod, ldo, out_row_group, g_gemm_flags, 0, rope_cos, rope_sin, rope_mod, rope_cols};
     if (g_gemm_flags & 16) p.lda = 0;
     if (g_gemm_flags & 32) p.ldw = 0;
     const int NCU = ufm_device_cu_count();  // whole rounds of the one-block-per-CU 8-phase kernel

@@ -13,6 +13,11 @@ struct GemmArgs {
     int act, ldres, res_row_mod, ldo, out_row_group;
     int debug;    // diagnostics only (tools/): 1 = every block reads tile (0,0), 2 = no DMA
     int m_begin;  // the launch covers rows [m_begin, M) (hybrid 256x256 + 128x128 split of one GEMM); row indices stay absolute
+    // fused RoPE-2D (ufm_gemm_bf16_rope, rope.hip): columns [0, rope_cols) of the bf16 output are rotated per 64-wide head with
+    // the fp32 tables [rope_mod][64] indexed by row % rope_mod; null tables = no rotation
+    const float* rope_cos;
+    const float* rope_sin;
+    int rope_mod, rope_cols;
 };
 
 namespace {
@@ -107,11 +112,20 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& p, f32x4 (&acc)[4][
             // bf16 output without residual: a lane converts 8 consecutive columns (two staged chunks) and stores 16 B,
             // a wave instruction covers 8 whole 128-B row segments
             const int r8 = lane >> 3, c8 = lane & 7;
+            const bool rope = p.rope_cos != nullptr && col0 < p.rope_cols;  // wave-uniform: the wave's 64 columns are one head
 #pragma unroll
             for (int pass = 0; pass < ROWS / 8; ++pass) {
                 const int r = pass * 8 + r8;
-                const f32x4 v0 = *(const f32x4*)(wave_lds + r * 256 + (((2 * c8) ^ (r & 15)) << 4));
-                const f32x4 v1 = *(const f32x4*)(wave_lds + r * 256 + (((2 * c8 + 1) ^ (r & 15)) << 4));
+                f32x4 v0 = *(const f32x4*)(wave_lds + r * 256 + (((2 * c8) ^ (r & 15)) << 4));
+                f32x4 v1 = *(const f32x4*)(wave_lds + r * 256 + (((2 * c8 + 1) ^ (r & 15)) << 4));
+                if (rope) {  // out[j] = v[j] cos[t][j] + v[j ^ 16] sin[t][j]: the partner columns are 4 chunks away in the same staged row
+                    const f32x4 q0 = *(const f32x4*)(wave_lds + r * 256 + ((((2 * c8) ^ 4) ^ (r & 15)) << 4));
+                    const f32x4 q1 = *(const f32x4*)(wave_lds + r * 256 + ((((2 * c8 + 1) ^ 4) ^ (r & 15)) << 4));
+                    const float* ct = p.rope_cos + (size_t)(min(row0 + r, p.M - 1) % p.rope_mod) * 64 + c8 * 8;
+                    const float* st = p.rope_sin + (size_t)(min(row0 + r, p.M - 1) % p.rope_mod) * 64 + c8 * 8;
+                    v0 = v0 * *(const f32x4*)ct + q0 * *(const f32x4*)st;
+                    v1 = v1 * *(const f32x4*)(ct + 4) + q1 * *(const f32x4*)(st + 4);
+                }
                 const int row = row0 + r;
                 int orow = row;
                 if (!PLAIN) {

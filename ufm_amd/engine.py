@@ -81,6 +81,39 @@ class _Blk:
             self.qscale = torch.cat([torch.full((d,), 0.125 * LOG2E), torch.ones(2 * d)]).to(device=dev, dtype=torch.float32)
 
 
+def _cat_linear(*lins: nn.Linear) -> nn.Linear:
+    """Several Linears over the same input as one (rows of the weights stacked): projk | projv -> one K|V GEMM."""
+    out = nn.Linear(lins[0].in_features, sum(l.out_features for l in lins), bias=lins[0].bias is not None)
+    with torch.no_grad():
+        out.weight.copy_(torch.cat([l.weight.detach().float().cpu() for l in lins], dim=0))
+        if out.bias is not None:
+            out.bias.copy_(torch.cat([l.bias.detach().float().cpu() for l in lins], dim=0))
+    return out
+
+
+class _XBlk(_Blk):
+    """Packed CrossBlockParams: the self-attention half is a _Blk (norm1/attn/ls1, norm3 -> n2, mlp, ls3 -> ls2)."""
+
+    def __init__(self, blk, dev, wdt, split: bool = False):
+        self.n1w, self.n1b = _f32(blk.norm1.weight, dev), _f32(blk.norm1.bias, dev)
+        self.n2w, self.n2b = _f32(blk.norm3.weight, dev), _f32(blk.norm3.bias, dev)   # the MLP's norm
+        self.qkv, self.proj = _Lin(blk.attn.qkv, dev, wdt, split), _Lin(blk.attn.proj, dev, wdt, split)
+        self.fc1, self.fc2 = _Lin(blk.mlp.fc1, dev, wdt, split), _Lin(blk.mlp.fc2, dev, wdt, split)
+        g = lambda m: _f32(m.gamma, dev) if hasattr(m, "gamma") else None  # noqa: E731
+        self.ls1, self.ls2 = g(blk.ls1), g(blk.ls3)
+        self.lsx = g(blk.ls2)                                                        # the cross-attention's LayerScale
+        d = self.qkv.n // 3
+        self.qscale = None
+        if wdt == torch.bfloat16 and not split:
+            self.qscale = torch.cat([torch.full((d,), 0.125 * LOG2E), torch.ones(2 * d)]).to(device=dev, dtype=torch.float32)
+        self.nyw, self.nyb = _f32(blk.norm_y.weight, dev), _f32(blk.norm_y.bias, dev)
+        self.nxw, self.nxb = _f32(blk.norm2.weight, dev), _f32(blk.norm2.bias, dev)   # the cross-attention's query norm
+        ca = blk.cross_attn
+        self.q = _Lin(ca.projq, dev, wdt, split)
+        self.kv = _Lin(_cat_linear(ca.projk, ca.projv), dev, wdt, split)
+        self.projx = _Lin(ca.proj, dev, wdt, split)
+
+
 class _Conv:
     """Conv2d packed [Cout][KH][KW][Cin]; ConvTranspose2d(k == s) packed [(kh,kw,co)][Cin].
     split=True stores the weight pre-split in the UFM_BF16X2 format for the bf16x3 kernel."""
@@ -210,10 +243,15 @@ class Engine:
         info = m.info_sharing
         self.Di, self.info_heads, self.info_indices = info.dim, info.num_heads, list(info.indices)
         self.info_proj = _Lin(info.proj_embed, dev, wdt) if isinstance(info.proj_embed, nn.Linear) else None
-        self.info_blocks = [_Blk(b, dev, wdt, self.trunk_x3) for b in info.self_attention_blocks]
         self.info_norm = (_f32(info.norm.weight, dev), _f32(info.norm.bias, dev))
-        if info.max_num_views < 2:
-            raise ValueError("info sharing needs max_num_views >= 2")
+        self.info_cross = hasattr(info, "multi_view_branches")  # the cross-attention variant (ufm.py:193, "cross_attention")
+        if self.info_cross:
+            self.info_branches = [[_XBlk(b, dev, wdt, self.trunk_x3) for b in branch] for branch in info.multi_view_branches]
+            self.rope_freq = info.rope_freq
+        else:
+            self.info_blocks = [_Blk(b, dev, wdt, self.trunk_x3) for b in info.self_attention_blocks]
+            if info.max_num_views < 2:
+                raise ValueError("info sharing needs max_num_views >= 2")
         # DPT heads: exact-fp32 MFMA in "parity"; bf16x3 split precision (UFM_BF16X2 activations) in "fast"
         self.head_split = self.numerics in ("fast", "precise", "parity_x3heads")
         self.heads = {"head1": _Head(m.head1, dev, self.head_split)}
@@ -329,6 +367,36 @@ class Engine:
             self._tables[key] = torch.cat([t[0:1].expand(Np, -1), t[1:2].expand(Np, -1)], dim=0).contiguous().to(self.dev)
         return self._tables[key]
 
+    def _rope_tables(self, gh: int, gw: int):
+        """cos / signed-sin tables [gh*gw][64] of the CroCo RoPE-2D for one head (rope.hip): first 32 columns rotate with the
+        token's y index, the last 32 with its x index; inside a half, pair (j, j ^ 16) shares theta = pos / freq^(2 (j % 16) / 32)."""
+        key = ("rope", gh, gw, self.rope_freq)
+        if key not in self._tables:
+            ys, xs = torch.meshgrid(torch.arange(gh, dtype=torch.float64), torch.arange(gw, dtype=torch.float64), indexing="ij")
+            pos = torch.stack([ys.reshape(-1), xs.reshape(-1)], dim=1)                       # (Np, 2) = (y, x)
+            inv = 1.0 / (self.rope_freq ** (torch.arange(0, 32, 2, dtype=torch.float64) / 32))  # 16 frequencies
+            cos, sin = torch.zeros(gh * gw, 64, dtype=torch.float64), torch.zeros(gh * gw, 64, dtype=torch.float64)
+            for half in range(2):
+                f = pos[:, half : half + 1] * inv                                               # (Np, 16)
+                f = torch.cat([f, f], dim=1)                                                    # (Np, 32)
+                sign = torch.cat([-torch.ones(16, dtype=torch.float64), torch.ones(16, dtype=torch.float64)])
+                cos[:, half * 32 : half * 32 + 32] = f.cos().float().double()                   # (the oracle rounds cos / sin to fp32)
+                sin[:, half * 32 : half * 32 + 32] = f.sin().float().double() * sign
+            self._tables[key] = (cos.float().contiguous().to(self.dev), sin.float().contiguous().to(self.dev))
+        return self._tables[key]
+
+    def linear_rope(self, x, lin: _Lin, M: int, out, rope, rope_cols: int, gamma=None):
+        """Projection whose first ``rope_cols`` output columns (q / k heads) get RoPE-2D: fused into the GEMM epilogue in
+        "fast" (ufm_gemm_bf16_rope), the standalone in-place kernel after the Linear in the fp32 / split numerics."""
+        if rope is None:
+            return self.linear(x, lin, M, out, gamma=gamma)
+        cos, sin, mod = rope
+        if lin.w.dim() == 2 and lin.w.dtype == torch.bfloat16:
+            hip.gemm_bf16(x, lin.w, M, lin.n, lin.k, out, bias=lin.b, gamma=gamma, rope=(cos, sin, mod, rope_cols))
+        else:
+            self.linear(x, lin, M, out, gamma=gamma)
+            hip.rope2d(out, M, lin.n, 0, rope_cols, cos, sin, mod)
+
     def linear(self, x, lin: _Lin, M: int, out, *, act=hip.ACT_NONE, gamma=None, res=None, res_row_mod=0, out_row_group=0, lda=None):
         """out = epilogue(x @ W^T): bf16 MFMA GEMM in 'fast', the bf16x3 split form in 'precise', exact-fp32 MFMA (conv
         kernel as dense GEMM) in 'parity'."""
@@ -402,6 +470,59 @@ class Engine:
             else:
                 self.linear(hid, w.fc2, M, x, gamma=w.ls2, res=x)
             on_block(i, x)
+
+    def _view_major_tables(self, B: int, Np: int):
+        key = ("vm", B, Np)
+        if key not in self._tables:
+            r = torch.arange(2 * B * Np, dtype=torch.int32)
+            self._tables[key] = dict(v1=r[: B * Np].contiguous().to(self.dev), v2=r[B * Np :].contiguous().to(self.dev), all=r.to(self.dev))
+        return self._tables[key]
+
+    def _cross_blocks(self, y, B: int, Np: int, gh: int, gw: int, on_block) -> None:
+        """The cross-attention info-sharing variant ([U] MultiViewCrossAttentionTransformerIFR, ufm.py:193): ``y`` holds the
+        fp32 residual streams of both views, (view, pair, patch) rows.  Layer l updates BOTH views from the layer-(l-1)
+        tokens: view v's block = self-attention over its own Np tokens, cross-attention of its queries to norm_y(the OTHER
+        view's previous-layer tokens), MLP.  RoPE-2D (if configured) rotates q / k of both attentions: fused into the
+        projection GEMM's epilogue in "fast".  Self-attention of the two views' B images runs through the same kernels as the
+        encoder; the cross-attention through the two-source entry points (ufm_cross_attention_*)."""
+        Di, heads, Mv = self.Di, self.info_heads, B * Np
+        x3 = self.trunk_x3
+        fmt = hip.BF16X2 if x3 else (hip.BF16 if self.adt == torch.bfloat16 else hip.F32)
+        tb = (lambda name, rows, cols: self.buf(name + "_x2", (2, rows, cols), torch.bfloat16)) if x3 else (lambda name, rows, cols: self.buf(name, (rows, cols), self.adt))
+        xn, qkv, ao, hid = tb("xc_xn", Mv, Di), tb("xc_qkv", Mv, 3 * Di), tb("xc_ao", Mv, Di), tb("xc_hid", Mv, self.info_branches[0][0].fc1.n)
+        qb, kvb = tb("xc_q", Mv, Di), tb("xc_kv", Mv, 2 * Di)
+        yn = [tb(f"xc_yn{v}", Mv, Di) for v in range(2)]
+        rope = None
+        if self.rope_freq:
+            cos, sin = self._rope_tables(gh, gw)
+            rope = (cos, sin, Np)
+        xs = [y[:Mv], y[Mv:]]
+        cols = lambda t, c0, c1: (t[0][:, c0:c1] if x3 else t[:, c0:c1])  # noqa: E731  (column view: hi plane of a split buffer)
+        for layer in range(len(self.info_branches[0])):
+            blks = [self.info_branches[v][layer] for v in range(2)]
+            for v in range(2):  # the memory of view v's cross-attention: norm_y of the OTHER view's previous-layer tokens
+                hip.layernorm(xs[1 - v], Di, None, Mv, Di, blks[v].nyw, blks[v].nyb, 1e-6, yn[v], split=x3)
+            for v in range(2):
+                w, x = blks[v], xs[v]
+                # self-attention
+                hip.layernorm(x, Di, None, Mv, Di, w.n1w, w.n1b, 1e-6, xn, split=x3)
+                self.linear_rope(xn, w.qkv, Mv, qkv, rope, 2 * Di, gamma=w.qscale)
+                if x3:
+                    hip.attention_x3(qkv, ao, B, Np, heads, 0.125)
+                else:
+                    hip.attention(qkv, ao, B, Np, heads, 0.0 if w.qscale is not None else 0.125)
+                self.linear(ao, w.proj, Mv, x, gamma=w.ls1, res=x)
+                # cross-attention: queries from this view, keys / values from the other view's normed tokens
+                hip.layernorm(x, Di, None, Mv, Di, w.nxw, w.nxb, 1e-6, xn, split=x3)
+                self.linear_rope(xn, w.q, Mv, qb, rope, Di)
+                self.linear_rope(yn[v], w.kv, Mv, kvb, rope, Di)
+                hip.cross_attention(cols(qb, 0, Di), Di, cols(kvb, 0, Di), cols(kvb, Di, 2 * Di), 2 * Di, cols(ao, 0, Di), Di, B, Np, Np, heads, 0.125, fmt)
+                self.linear(ao, w.projx, Mv, x, gamma=w.lsx, res=x)
+                # MLP
+                hip.layernorm(x, Di, None, Mv, Di, w.n2w, w.n2b, 1e-6, xn, split=x3)
+                self.linear(xn, w.fc1, Mv, hid, act=hip.ACT_GELU)
+                self.linear(hid, w.fc2, Mv, x, gamma=w.ls2, res=x)
+            on_block(layer, y)
 
     def _encode(self, patches, B2: int, H: int, W: int):
         gh, gw = H // self.P, W // self.P
@@ -667,6 +788,9 @@ class Engine:
         last_i = len(self.enc_blocks) - 1
         lvl0 = None
         enc_info = self.buf("enc_info", (B * 2 * Np, D), self.adt)
+        # info-sharing token order: global attention (pair, view, patch) -- one pair's joint tokens contiguous; the
+        # cross-attention variant (view, pair, patch) -- one view's tokens of the whole batch contiguous
+        enc_info_rows = idx["enc_all"] if self.info_cross else idx["enc_info"]
 
         def on_enc(i, xx):
             nonlocal enc_first, lvl0
@@ -678,39 +802,49 @@ class Engine:
                     enc_first = self.buf("enc_first", (B2 * Np, D))
                     hip.layernorm(xx, D, idx["enc_all"], B2 * Np, D, nw, nb, 1e-6, enc_first)
             if i == self.enc_indices[-1]:
-                hip.layernorm(xx, D, idx["enc_info"], B * 2 * Np, D, nw, nb, 1e-6, enc_info)
+                hip.layernorm(xx, D, enc_info_rows, B * 2 * Np, D, nw, nb, 1e-6, enc_info)
                 lvl0 = self.level_ln(xx, D, idx["enc_v1"], B * Np, nw, nb, "lvl0")
 
         blocks = self.enc_blocks[: self.enc_indices[-1] + 1]  # blocks past the last returned index never matter
         self._blocks(blocks, x, n_enc, N, D, self.enc_heads, on_enc, needs_x=lambda i: (self.refine and i == self.enc_indices[0]) or i == self.enc_indices[-1])
 
-        # ---- info sharing: joint attention over the 2*Np tokens of each pair ----
+        # ---- info sharing ----
         M2 = B * 2 * Np
         y = self.buf("info_x", (M2, Di))
-        vpe = self._view_pe_table(Np)
+        vpe = None if self.info_cross else self._view_pe_table(Np)
         if self.info_proj is None:
             src32 = enc_info if enc_info.dtype == torch.float32 else None
             if src32 is None:
                 src32 = self.buf("enc_info32", (M2, D))
-                hip.layernorm(x, D, idx["enc_info"], M2, D, nw, nb, 1e-6, src32)
+                hip.layernorm(x, D, enc_info_rows, M2, D, nw, nb, 1e-6, src32)
             hip.add_rows(src32, D, vpe, 2 * Np, y, Di, 0, M2, Di)
         elif self.numerics == "fast":
-            hip.gemm_bf16(enc_info, self.info_proj.w, M2, Di, D, y, bias=self.info_proj.b, res=vpe, res_row_mod=2 * Np)
+            hip.gemm_bf16(enc_info, self.info_proj.w, M2, Di, D, y, bias=self.info_proj.b, res=vpe, res_row_mod=2 * Np if vpe is not None else 0)
+        elif vpe is None:
+            self.linear(enc_info, self.info_proj, M2, y)
         else:
             tmp = self.buf("info_tmp", (M2, Di))
             self.linear(enc_info, self.info_proj, M2, tmp)
             hip.add_rows(tmp, Di, vpe, 2 * Np, y, Di, 0, M2, Di)
         inw, inb = self.info_norm
         inter: List[torch.Tensor] = []
+        if self.info_cross:
+            iv = self._view_major_tables(B, Np)
+            info_v1, info_v2, info_all = iv["v1"], iv["v2"], iv["all"]
+        else:
+            info_v1, info_v2, info_all = idx["info_v1"], idx["info_v2"], idx["info_all"]
 
         def on_info(i, yy):
             if i in self.info_indices:
-                inter.append(self.level_ln(yy, Di, idx["info_v1"], B * Np, inw, inb, f"lvl_i{len(inter)}"))
+                inter.append(self.level_ln(yy, Di, info_v1, B * Np, inw, inb, f"lvl_i{len(inter)}"))
 
-        self._blocks(self.info_blocks, y, B, 2 * Np, Di, self.info_heads, on_info, needs_x=lambda i: i in self.info_indices)
+        if self.info_cross:
+            self._cross_blocks(y, B, Np, gh, gw, on_info)
+        else:
+            self._blocks(self.info_blocks, y, B, 2 * Np, Di, self.info_heads, on_info, needs_x=lambda i: i in self.info_indices)
         if len(inter) != 2:
             raise ValueError("info_sharing.indices must name two blocks (ufm.py:605-606 reads intermediates [0] and [1])")
-        lvl3 = self.level_ln(y, Di, idx["info_v1"], B * Np, inw, inb, "lvl3")
+        lvl3 = self.level_ln(y, Di, info_v1, B * Np, inw, inb, "lvl3")
         levels = [lvl0, inter[0], inter[1], lvl3]  # ufm.py:603-608 (view-1 pyramid only; view 2's is never decoded)
         dims = [D, Di, Di, Di]
 
@@ -745,16 +879,16 @@ class Engine:
                 # torch.cat([enc_first | info_final], channels), views stacked on batch (ufm.py:955-964), built in the split
                 # format by the two LayerNorm launches themselves; the MLP is two 1x1 bf16x3 convolutions over the rows
                 cat = enc_first
-                hip.layernorm(y, Di, idx["info_all"], B2 * Np, Di, inw, inb, 1e-6, cat[0][:, D:], ldo=C1, split=True)
+                hip.layernorm(y, Di, info_all, B2 * Np, Di, inw, inb, 1e-6, cat[0][:, D:], ldo=C1, split=True)
                 hidden = self.buf("cls_hid_x2", (2, B2 * Np, self.cls_fc1.n), torch.bfloat16)
                 self.conv(cat, 1, 1, B2 * Np, self.cls_fc1, hidden, act=hip.ACT_GELU)
                 tok = self.buf("cls_tok_x2", (2, B2 * Np, self.cls_fc2.n), torch.bfloat16)
                 self.conv(hidden, 1, 1, B2 * Np, self.cls_fc2, tok)
             else:
                 lvl3a = self.buf("lvl3_v1_f32", (B * Np, Di))
-                hip.layernorm(y, Di, idx["info_v1"], B * Np, Di, inw, inb, 1e-6, lvl3a)
+                hip.layernorm(y, Di, info_v1, B * Np, Di, inw, inb, 1e-6, lvl3a)
                 lvl3b = self.buf("lvl3_v2", (B * Np, Di))
-                hip.layernorm(y, Di, idx["info_v2"], B * Np, Di, inw, inb, 1e-6, lvl3b)
+                hip.layernorm(y, Di, info_v2, B * Np, Di, inw, inb, 1e-6, lvl3b)
                 cat = self.buf("cls_in", (B2 * Np, C1))
                 # torch.cat along channels == strided row copies: enc_first | info_final, views stacked on batch
                 hip.add_rows(enc_first, D, None, 0, cat, C1, 0, B2 * Np, D)

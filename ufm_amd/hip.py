@@ -30,6 +30,11 @@ SIGNATURES = {
     "ufm_patchify": [_vp, _i, _i, _i, _i, _i, _i, _fp3, _fp3, _vp, _i, _i, _vp],
     "ufm_resize_antialias": [_vp, _i, _i, _i, _i, _i, _fp3, _fp3, _vp, _i, _i, _vp, _vp],
     "ufm_gemm_bf16": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp],
+    "ufm_gemm_bf16_rope": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp],
+    "ufm_rope2d": [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
+    "ufm_cross_attention_bf16": [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp],
+    "ufm_cross_attention_f32": [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp],
+    "ufm_cross_attention_bf16x3": [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp],
     "ufm_debug_set_gemm_variant": [_i],
     "ufm_debug_set_gemm_flags": [_i],
     "ufm_debug_set_gemm_tile_rows": [_i],
@@ -178,7 +183,16 @@ def resize_antialias(img: torch.Tensor, layout: int, B: int, H: int, W: int, sca
     _check(lib().ufm_resize_antialias(_p(img), in_dtype, layout, B, H, W, _f3(scale3), _f3(shift3), _p(out), Ho, Wo, _p(tmp), _stream()), "ufm_resize_antialias")
 
 
-def gemm_bf16(A, W, M, N, K, out, *, bias=None, act=ACT_NONE, gamma=None, res=None, ldres=0, res_row_mod=0, lda=None, ldw=None, ldo=None, out_row_group=0):
+def gemm_bf16(A, W, M, N, K, out, *, bias=None, act=ACT_NONE, gamma=None, res=None, ldres=0, res_row_mod=0, lda=None, ldw=None, ldo=None, out_row_group=0, rope=None):
+    """rope = (cos_table, sin_table, mod, cols): RoPE-2D fused into the epilogue on output columns [0, cols) (ufm_gemm_bf16_rope)."""
+    if rope is not None:
+        _t("ufm_gemm_bf16", (2.0 * M * N * K, f"M{M} N{N} K{K} bf16 out + RoPE"))
+        _check(
+            lib().ufm_gemm_bf16_rope(_p(A), lda or K, _p(W), ldw or K, M, N, K, _p(bias), act, _p(gamma), _p(res), ldres or N, res_row_mod, _p(out), _dt(out), ldo or N, out_row_group,
+                                     _p(rope[0]), _p(rope[1]), int(rope[2]), int(rope[3]), _stream()),
+            "ufm_gemm_bf16_rope",
+        )
+        return
     _t("ufm_gemm_bf16", (2.0 * M * N * K, f"M{M} N{N} K{K} " + ("f32 += (read-modify-write)" if (out.dtype == torch.float32 and res is not None and res_row_mod == 0) else
                                                              "f32 out" if out.dtype == torch.float32 else "bf16 out" + (" GELU" if act == ACT_GELU else ""))))
     _check(
@@ -230,6 +244,25 @@ def attention_x3(qkv, out, B, N, H, scale):
     """Attention on the split format: qkv (2, B*N, 3*H*64), out (2, B*N, H*64) bf16 planes."""
     _t("ufm_attention_bf16x3", 4.0 * B * H * N * N * 64)
     _check(lib().ufm_attention_bf16x3(_p(qkv), _p(out), B, N, H, scale, _stream()), "ufm_attention_bf16x3")
+
+
+def rope2d(x, rows, ld, col0, ncols, cos_table, sin_table, mod):
+    """In-place RoPE-2D on columns [col0, col0 + ncols) of x: fp32 / bf16 (rows, ld), or split planes (2, rows, ld)."""
+    fmt = BF16X2 if (x.dtype == torch.bfloat16 and x.dim() == 3) else _dt(x)
+    _check(lib().ufm_rope2d(_p(x), fmt, rows, ld, col0, ncols, _p(cos_table), _p(sin_table), mod, _stream()), "ufm_rope2d")
+
+
+def cross_attention(q, ldq, k, v, ldkv, out, ldo, B, Nq, Nk, H, scale, fmt):
+    """Two-source attention; q / k / v / out may be column views of wider buffers (pass their data pointers through
+    tensors whose storage offset is already applied).  fmt: F32, BF16 or BF16X2."""
+    name = {F32: "ufm_cross_attention_f32", BF16: "ufm_cross_attention_bf16", BF16X2: "ufm_cross_attention_bf16x3"}[fmt]
+    _t({F32: "ufm_attention_f32", BF16: "ufm_attention_bf16", BF16X2: "ufm_attention_bf16x3"}[fmt], 4.0 * B * H * Nq * Nk * 64)
+    rc = getattr(lib(), name)(_p(q), ldq, _p(k), _p(v), ldkv, _p(out), ldo, B, Nq, Nk, H, scale, _stream())
+    if TIMER is not None and TIMER._open is not None:
+        TIMER.end()
+        TIMER._open = None
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (rc={rc}): {lib().ufm_last_error().decode()}")
 
 
 def conv2d(x, B, H, W, Cin, weight, Cout, KH, KW, stride, pad, out, zero_page, *, relu_in=False, bias=None, act=ACT_NONE, gamma=None, res1=None, res2=None, shuffle=0):

@@ -179,7 +179,79 @@ class GlobalAttentionInfoSharing(_Holder):
         self.indices = list(indices) if indices is not None else [depth // 2 - 1, (3 * depth) // 4 - 1]
 
 
-INFO_SHARING_CLASSES = {"global_attention": (None, GlobalAttentionInfoSharing)}
+class _CrossAttnParams(_Holder):
+    def __init__(self, dim: int, num_heads: int, qkv_bias: bool = True):
+        super().__init__()
+        self.num_heads = num_heads
+        self.projq = nn.Linear(dim, dim, bias=qkv_bias)
+        self.projk = nn.Linear(dim, dim, bias=qkv_bias)
+        self.projv = nn.Linear(dim, dim, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+
+class CrossBlockParams(_Holder):
+    """[U] CrossAttentionBlock (CroCo decoder block): self-attention, cross-attention to the other view, MLP."""
+
+    def __init__(self, dim: int, num_heads: int, mlp_ratio: float = 4.0, qkv_bias: bool = True, init_values: Optional[float] = None, norm_cross_tokens: bool = True):
+        super().__init__()
+        ls = (lambda: _Gamma(dim, init_values)) if init_values is not None else (lambda: nn.Identity())
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _AttnParams(dim, num_heads, qkv_bias)
+        self.ls1 = ls()
+        self.norm_y = nn.LayerNorm(dim, eps=1e-6) if norm_cross_tokens else nn.Identity()
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.cross_attn = _CrossAttnParams(dim, num_heads, qkv_bias)
+        self.ls2 = ls()
+        self.norm3 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _MlpParams(dim, int(dim * mlp_ratio))
+        self.ls3 = ls()
+
+
+class CrossAttentionInfoSharing(_Holder):
+    """``INFO_SHARING_CLASSES["cross_attention"][1](**info_sharing_kwargs)`` (ufm.py:193): one branch of CroCo-style
+    decoder blocks per view, each block attending to its own view and to the other view's tokens of the previous layer;
+    ``rope_freq`` turns on RoPE-2D on q / k (upstream: a callable `custom_positional_encoding`).  The third-party class is
+    absent from the reference: restated, **parity unpinned** (oracle/uniception_ref.py)."""
+
+    def __init__(
+        self,
+        name: str = "cross_attention",
+        input_embed_dim: int = 1024,
+        num_views: int = 2,
+        size: Optional[str] = None,
+        depth: int = 12,
+        dim: int = 768,
+        num_heads: int = 12,
+        mlp_ratio: float = 4.0,
+        qkv_bias: bool = True,
+        init_values: Optional[float] = None,
+        indices: Optional[List[int]] = None,
+        norm_intermediate: bool = True,
+        norm_cross_tokens: bool = True,
+        rope_freq: Optional[float] = None,
+        **_: Any,
+    ):
+        super().__init__()
+        if size is not None:
+            depth, dim, num_heads = {"base": (12, 768, 12), "large": (24, 1024, 16)}[size]
+        if not norm_intermediate:
+            raise NotImplementedError("norm_intermediate=False is not used by UFM")
+        if num_views != 2:
+            raise NotImplementedError("UFM shares information between exactly two views (ufm.py:390)")
+        if not norm_cross_tokens:
+            raise NotImplementedError("norm_cross_tokens=False is not built")
+        self.name, self.input_embed_dim, self.num_views = name, input_embed_dim, num_views
+        self.depth, self.dim, self.num_heads = depth, dim, num_heads
+        self.rope_freq = float(rope_freq) if rope_freq else None
+        self.proj_embed = nn.Linear(input_embed_dim, dim, bias=True) if input_embed_dim != dim else nn.Identity()
+        self.multi_view_branches = nn.ModuleList(
+            [nn.ModuleList([CrossBlockParams(dim, num_heads, mlp_ratio, qkv_bias, init_values, norm_cross_tokens) for _ in range(depth)]) for _ in range(num_views)]
+        )
+        self.norm = nn.LayerNorm(dim, eps=1e-6)
+        self.indices = list(indices) if indices is not None else [depth // 2 - 1, (3 * depth) // 4 - 1]
+
+
+INFO_SHARING_CLASSES = {"global_attention": (None, GlobalAttentionInfoSharing), "cross_attention": (None, CrossAttentionInfoSharing)}
 
 
 class _RCUParams(_Holder):
@@ -330,6 +402,7 @@ def init_weights_(model: nn.Module, seed: int = 0) -> nn.Module:
 
     g = torch.Generator().manual_seed(seed)
     convt = re.compile(r"act_(1|2)_postprocess\.1\.weight$")
+    group_norm_weights = {f"{mn}.weight" for mn, m in model.named_modules() if isinstance(m, nn.GroupNorm)}  # (moge_conv head)
     with torch.no_grad():
         for name, p in sorted(model.named_parameters(), key=lambda kv: kv[0]):
             cpu = torch.empty(p.shape, dtype=torch.float32)
@@ -338,7 +411,7 @@ def init_weights_(model: nn.Module, seed: int = 0) -> nn.Module:
                 cpu = torch.randn(p.shape, generator=g) * (1.0 / fan_in**0.5)
             elif name.endswith("gamma"):
                 cpu = 1.0 + 0.1 * torch.randn(p.shape, generator=g)
-            elif "norm" in name and name.endswith("weight"):
+            elif ("norm" in name and name.endswith("weight")) or name in group_norm_weights:
                 cpu = 1.0 + 0.1 * torch.randn(p.shape, generator=g)
             elif name.endswith("classification_bias"):
                 cpu = 0.1 * torch.randn(p.shape, generator=g)

@@ -70,7 +70,7 @@ class UniFlowMatch(UniFlowMatchModelsBase, PyTorchModelHubMixin):
         if encoder_str != "dinov2":
             raise NotImplementedError(f"encoder {encoder_str!r}: only the DINOv2 ViT encoder is built")
         if info_sharing_str not in M.INFO_SHARING_CLASSES:
-            raise NotImplementedError(f"info_sharing_str {info_sharing_str!r}: only 'global_attention' is built (SURVEY 8(f) rank 4)")
+            raise NotImplementedError(f"info_sharing_str {info_sharing_str!r}: built are {sorted(M.INFO_SHARING_CLASSES)}")
         self.encoder: nn.Module = M.DINOv2Encoder(**encoder_kwargs)
         self.head_type = head_type
         self.info_sharing: nn.Module = M.INFO_SHARING_CLASSES[info_sharing_str][1](**info_sharing_kwargs)
