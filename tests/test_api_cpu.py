@@ -84,8 +84,11 @@ def test_error_behaviour_without_gpu():
         m.predict_correspondences_batched(z.int(), z.int())
     with pytest.raises(RuntimeError, match="GPU only"):  # the product has no CPU path
         m.predict_correspondences_batched(z, z)
-    with pytest.raises(NotImplementedError):
-        ufm_amd.UniFlowMatchConfidence(**{**ufm_amd.ufm_tiny_config(), "info_sharing_str": "cross_attention"})
+    with pytest.raises(NotImplementedError, match="built are"):  # an info-sharing variant that does not exist
+        ufm_amd.UniFlowMatchConfidence(**{**ufm_amd.ufm_tiny_config(), "info_sharing_str": "alternating_attention"})
+    xa = ufm_amd.UniFlowMatchConfidence(**{**ufm_amd.ufm_tiny_config(), "info_sharing_str": "cross_attention",
+                                           "info_sharing_kwargs": dict(input_embed_dim=128, depth=2, dim=128, num_heads=2)})
+    assert len(xa.info_sharing.multi_view_branches) == 2 and "info_sharing.multi_view_branches.1.1.cross_attn.projq.weight" in xa.state_dict()
     with pytest.raises(RuntimeError, match="parameter container"):
         m.encoder(None)
 
