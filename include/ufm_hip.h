@@ -209,6 +209,8 @@ int ufm_attention_f32(const float* qkv, float* out, int B, int N, int H, float s
  *   in  : fp32 [B][H][W][Cin]         weight: fp32 [Cout][KH][KW][Cin]   (pre-packed)
  *   out : fp32 [B][Ho][Wo][Cout], Ho = (H + 2*pad - KH)/stride + 1
  *   v = conv(relu_in ? relu(in) : in) + bias ; v = act(v) ; v *= gamma[n] ; v += res1 + res2
+ *   relu_in is a flag word: bit 0 = ReLU on the input, bit 1 (value 2) = padding_mode "replicate" (out-of-range taps read the
+ *   nearest edge pixel; [U] MoGeConvFeature's convolutions) instead of zero padding; the same in ufm_conv2d_nhwc_bf16x3.
  *   (res1/res2: fp32, same shape as out, may be NULL, may alias out)
  *   shuffle > 0: ConvTranspose(k=s=shuffle) mode: weight is [(kh,kw,co)][Cin] with
  *   Cout = shuffle*shuffle*Co; element (b,y,x,(kh,kw,co)) is stored at
@@ -344,6 +346,27 @@ int ufm_resize_nearest_nhwc(const void* in, int dtype, int B, int H, int W, int 
                             int c_off, void* stream);
 int ufm_unet_combine(const float* cls, const void* unet, int unet_dtype, int N, int HW, int ldu, const float* w1,
                      const float* b1, const float* w2, const float* b2, int method, float* out, void* stream);
+
+/* =====================================================================================
+ * The "moge_conv" prediction head ([U] uniception MoGeConvFeature = the convolutional head of MoGe: per-level 1x1
+ * projections summed, three x2 stages {concat view-plane uv, ConvTranspose2d(k=s=2), conv3x3, residual conv blocks with
+ * GroupNorm}, bilinear resize to the target, concat uv, conv3x3 -> ReLU -> conv1x1; call site models/ufm.py:266-267).
+ * PARITY UNPINNED: the class is absent from the reference, restated in oracle/uniception_ref.py.  Its convolutions run on
+ * ufm_conv2d_nhwc_f32 / _bf16x3 (padding_mode "replicate": relu_in bit 1); these are the kernels in between (moge.hip),
+ * NHWC fp32 or UFM_BF16X2 (lo plane at B*H*W*ldc elements):
+ *   ufm_group_norm_nhwc:      nn.GroupNorm(groups, C)(x) (+ ReLU if relu), x [B][HW][ldc] (C channels used), two-stage
+ *                             deterministic statistics; partial_ws: ufm_group_norm_ws_floats(B, HW, groups) floats
+ *   ufm_fill_uv_nhwc:         channels [c_off, c_off+2) = normalized_view_plane_uv(W, H, aspect_ratio) of the pixel, the
+ *                             rest [c_off+2, ldc) = 0 (padding up to the conv kernels' 32-channel K chunk)
+ *   ufm_resize_bilinear_nhwc: F.interpolate(mode="bilinear", align_corners=False) of in [B][H][W][ldi] (C channels) into
+ *                             channels [c_off, c_off + C) of out [B][Ho][Wo][ldc]
+ * ===================================================================================== */
+int ufm_group_norm_nhwc(const void* in, int dtype, int B, int HW, int C, int ldc, int groups, const float* weight,
+                        const float* bias, float eps, int relu, void* out, float* partial_ws, void* stream);
+int ufm_group_norm_ws_floats(int B, int HW, int groups);
+int ufm_fill_uv_nhwc(void* out, int dtype, int B, int H, int W, int ldc, int c_off, float aspect_ratio, void* stream);
+int ufm_resize_bilinear_nhwc(const void* in, int dtype, int B, int H, int W, int C, int ldi, void* out, int Ho, int Wo, int ldc,
+                             int c_off, void* stream);
 
 /* Pixel shuffle for MLPFeature ([U], call site models/ufm.py:965): x [B*g*g][C*p*p] (column = (c, i, j)), fp32 or the
  * UFM_BF16X2 pair of planes (value = hi + lo) -> fp32 planar [B][C][g*p][g*p]. */

@@ -754,6 +754,83 @@ def test_gemm_fused_rope_matches_linear_then_rope(hip, M_mult, N, K, rope_cols):
         hip.gemm_bf16(A.to(DEV).bfloat16(), W.to(DEV).bfloat16(), M, N, K, torch.zeros(M, N, device=DEV), rope=(cos, sin, Np, rope_cols))
 
 
+# ---- the moge_conv head's kernels: replicate-padding convolution, GroupNorm, uv channels, bilinear (align_corners=False) ----
+@pytest.mark.parametrize("fmt", ["f32", "x3"])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,big", [(2, 9, 11, 32, 32, False), (1, 30, 30, 256, 256, True), (1, 37, 21, 64, 128, False)])
+def test_conv3x3_replicate_padding(hip, fmt, B, H, W, Cin, Cout, big):
+    """padding_mode="replicate" (relu_in flag bit 1) on the fp32 and the bf16x3 conv kernels, incl. the 8-phase 256x256 tile."""
+    x = rnd(B, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=(Cin * 9) ** -0.5)
+    b = rnd(Cout, seed=3, scale=0.1)
+    ref = F.conv2d(F.pad(x.double(), (1, 1, 1, 1), mode="replicate"), w.double(), b.double())
+    zero = torch.zeros(256, device=DEV)
+    if fmt == "f32":
+        out = torch.zeros(B, H, W, Cout, device=DEV)
+        hip.conv2d(nhwc(x).to(DEV), B, H, W, Cin, w.permute(0, 2, 3, 1).contiguous().to(DEV), Cout, 3, 3, 1, 1, out, zero, bias=b.to(DEV), replicate=True)
+        got, tol = out.cpu().permute(0, 3, 1, 2).double(), 2e-5
+    else:
+        if big:
+            hip.lib().ufm_debug_set_conv_variant(2)  # force the 8-phase kernel
+        out = torch.zeros(2, B, H, W, Cout, device=DEV, dtype=torch.bfloat16)
+        hip.conv2d_x3(split(nhwc(x)).to(DEV), B, H, W, Cin, split(w.permute(0, 2, 3, 1).contiguous()).to(DEV), Cout, 3, 3, 1, 1, out, zero, bias=b.to(DEV), replicate=True)
+        hip.lib().ufm_debug_set_conv_variant(0)
+        got, tol = unsplit(out.cpu()).permute(0, 3, 1, 2).double(), 4e-5
+    err = (got - ref).abs().max().item()
+    assert err <= tol * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("fmt", ["f32", "x3"])
+@pytest.mark.parametrize("B,H,W,C,G,relu", [(2, 9, 11, 64, 2, True), (1, 70, 33, 256, 8, True), (3, 5, 5, 32, 1, False), (1, 40, 40, 96, 3, True)])
+def test_group_norm_nhwc(hip, fmt, B, H, W, C, G, relu):
+    x = rnd(B, C, H, W, seed=1, scale=2.0) + 0.5
+    w, b = 1 + rnd(C, seed=2, scale=0.1), rnd(C, seed=3, scale=0.1)
+    ref = F.group_norm(x.double(), G, w.double(), b.double(), 1e-5)
+    if relu:
+        ref = F.relu(ref)
+    xin = nhwc(x)
+    if fmt == "x3":
+        xs = split(xin)
+        ref = F.group_norm(unsplit(xs).permute(0, 3, 1, 2).double(), G, w.double(), b.double(), 1e-5)
+        ref = F.relu(ref) if relu else ref
+        buf, out = xs.to(DEV), torch.zeros(2, B, H, W, C, device=DEV, dtype=torch.bfloat16)
+    else:
+        buf, out = xin.to(DEV), torch.zeros(B, H, W, C, device=DEV)
+    ws = torch.zeros(hip.group_norm_ws_floats(B, H * W, G), device=DEV)
+    hip.group_norm(buf, B, H * W, C, G, w.to(DEV), b.to(DEV), 1e-5, relu, out, ws)
+    got = (unsplit(out.cpu()) if fmt == "x3" else out.cpu()).permute(0, 3, 1, 2).double()
+    err = (got - ref).abs().max().item()
+    assert err <= 3e-5, err
+    again = torch.zeros_like(out)
+    hip.group_norm(buf, B, H * W, C, G, w.to(DEV), b.to(DEV), 1e-5, relu, again, ws)
+    assert torch.equal(again, out)  # deterministic statistics
+
+
+@pytest.mark.parametrize("fmt", ["f32", "x3"])
+def test_fill_uv_and_bilinear_resize_into_concat_buffer(hip, fmt):
+    """torch.cat([F.interpolate(x, (H, W), bilinear, align_corners=False), uv], dim=1) as MoGe builds it, in a 32-channel-padded
+    NHWC buffer: ufm_resize_bilinear_nhwc writes the x slot, ufm_fill_uv_nhwc the two uv channels and the zero padding."""
+    from oracle.uniception_ref import normalized_view_plane_uv
+
+    B, h, w, C, H, W = 2, 16, 24, 32, 45, 70
+    ldc = 64
+    x = rnd(B, C, h, w, seed=4)
+    xin = nhwc(x)
+    if fmt == "x3":
+        xs = split(xin)
+        x = unsplit(xs).permute(0, 3, 1, 2)
+        buf, out = xs.to(DEV), torch.full((2, B, H, W, ldc), 7.0, device=DEV, dtype=torch.bfloat16)
+    else:
+        buf, out = xin.to(DEV), torch.full((B, H, W, ldc), 7.0, device=DEV)
+    want_x = F.interpolate(x, (H, W), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    uv = normalized_view_plane_uv(W, H, W / H)
+    hip.resize_bilinear(buf, B, h, w, C, C, out, H, W, ldc, 0)
+    hip.fill_uv(out, B, H, W, ldc, C, W / H)
+    got = unsplit(out.cpu()) if fmt == "x3" else out.cpu()
+    assert (got[..., :C] - want_x).abs().max().item() <= (2e-5 if fmt == "x3" else 2e-6)
+    assert (got[..., C : C + 2] - uv.unsqueeze(0)).abs().max().item() <= 1e-6
+    assert got[..., C + 2 :].abs().max().item() == 0.0
+
+
 # ---- numerics "precise": the transformer's Linear layers and attention on the split format ----
 @pytest.mark.parametrize(
     "M,N,K,act,use_gamma,use_res,split_out",

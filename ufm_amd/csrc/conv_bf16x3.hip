@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void conv_x3_kernel(ConvX3Arg
         char* sa = smem + buf * STAGE_BYTES + wave * A_RPW * 64;  // A hi plane, this wave's rows
 #pragma unroll
         for (int i = 0; i < A_PIECES; ++i) {
-            const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+            int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+            if (p.replicate) iy = min(max(iy, 0), p.H - 1), ix = min(max(ix, 0), p.W - 1);
             const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             const uint16_t* src = ok ? p.in + (a_img[i] + (size_t)iy * p.W + ix) * p.Cin + c0 + a_chunk[i] : p.zero + a_chunk[i];
             const uint16_t* src_lo = ok ? src + p.in_plane : src;
@@ -285,7 +286,8 @@ extern "C" int ufm_conv2d_nhwc_bf16x3(const uint16_t* in, int B, int H, int W, i
     const long long Mout = shuffle ? M * shuffle * shuffle : M;
     ConvX3Args p{in, weight, bias, res1, res2, zero_page, out, out_relu,
                  (long long)B * H * W * Cin, (long long)Cout * KH * KW * Cin, Mout * Co,
-                 B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, (int)M, relu_in, act, shuffle, Co, 0};
+                 B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, (int)M, relu_in & 1, act, shuffle, Co, 0};
+    p.replicate = (relu_in >> 1) & 1;
     launch_conv_x3(p, passes, (hipStream_t)stream);
     UFM_CHECK_LAUNCH("ufm_conv2d_nhwc_bf16x3");
     return UFM_OK;

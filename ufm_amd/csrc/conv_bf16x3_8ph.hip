@@ -92,7 +92,8 @@ __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
         if (KIND & 1) {
 #pragma unroll
             for (int i = 0; i < XPR; ++i) {
-                const int iy = x_iy0[H][i] + ti.kh, ix = x_ix0[H][i] + ti.kw;
+                int iy = x_iy0[H][i] + ti.kh, ix = x_ix0[H][i] + ti.kw;
+                if (p.replicate) iy = min(max(iy, 0), p.H - 1), ix = min(max(ix, 0), p.W - 1);
                 const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
                 const uint16_t* src = ok ? p.in + ((x_img[H][i] + (unsigned)(iy * p.W + ix)) * (unsigned)p.Cin + (unsigned)ti.c0 + x_chunk[i]) : p.zero + x_chunk[i];
                 const uint16_t* src_lo = ok ? src + p.in_plane : src;

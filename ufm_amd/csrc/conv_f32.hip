@@ -35,6 +35,7 @@ struct ConvArgs {
     float* out;
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, M;
     int relu_in, act, shuffle, Co;
+    int replicate;  // padding_mode='replicate': out-of-range taps read the nearest edge pixel instead of zero
 };
 
 template <int BN>
@@ -86,7 +87,8 @@ __global__ __launch_bounds__(256, 2) void conv_f32_kernel(ConvArgs p) {
         char* sb = smem + buf * STAGE_BYTES + A_BYTES + wave * (WPIECES * 1024);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+            int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
+            if (p.replicate) iy = min(max(iy, 0), p.H - 1), ix = min(max(ix, 0), p.W - 1);
             const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             const float* src = ok ? p.in + (a_img[i] + (size_t)iy * p.W + ix) * p.Cin + c0 + a_chunk[i] : p.zero + a_chunk[i];
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(sa + i * 1024), 16, 0, 0);
@@ -215,7 +217,7 @@ extern "C" int ufm_conv2d_nhwc_f32(const float* in, int B, int H, int W, int Cin
     }
     const long long M = (long long)B * Ho * Wo;
     UFM_REQUIRE(M < (1ll << 31) && (long long)B * H * W * Cin < (1ll << 40), "ufm_conv2d_nhwc_f32: problem too large");
-    ConvArgs p{in, weight, bias, gamma, res1, res2, zero_page, out, B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, (int)M, relu_in, act, shuffle, Co};
+    ConvArgs p{in, weight, bias, gamma, res1, res2, zero_page, out, B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, (int)M, relu_in & 1, act, shuffle, Co, (relu_in >> 1) & 1};
     const int ntm = (int)((M + BM - 1) / BM);
     if (Cout % 128 == 0) {
         hipLaunchKernelGGL(conv_f32_kernel<128>, dim3(ntm * (Cout / 128)), dim3(256), 0, (hipStream_t)stream, p);

@@ -19,6 +19,7 @@ struct ConvX3Args {
     const float* gamma;    // per-output-channel scale after the activation (LayerScale / Q pre-scale) or null
     const float* res_f32;  // fp32 residual [M][Cout] added after gamma (may alias out_f32) or null
     float* out_f32;        // non-null: the result is stored as fp32 [M][Cout] instead of the split planes
+    int replicate;         // padding_mode='replicate': out-of-range taps read the nearest edge pixel instead of the zero page
 };
 
 static __device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }

@@ -121,7 +121,9 @@ class _Conv:
     def __init__(self, conv: nn.Module, dev, split: bool = False, cin_pad: int = 0, cout_pad: int = 0):
         w = conv.weight.detach().to(device=dev, dtype=torch.float32)
         self.b = _f32(conv.bias, dev) if conv.bias is not None else None
-        if cin_pad or cout_pad:  # zero-pad to the kernels' channel multiples (UNet: 3 input channels, 16 output channels)
+        if isinstance(conv, nn.ConvTranspose2d) and cin_pad > w.shape[0]:  # weight (cin, co, kh, kw): zero rows for the pad channels
+            w = torch.cat([w, torch.zeros((cin_pad - w.shape[0],) + tuple(w.shape[1:]), device=dev, dtype=torch.float32)], dim=0)
+        elif cin_pad or cout_pad:  # zero-pad to the kernels' channel multiples (UNet: 3 input channels, 16 output channels)
             assert isinstance(conv, nn.Conv2d)
             co, ci = w.shape[0], w.shape[1]
             wp = torch.zeros((max(co, cout_pad), max(ci, cin_pad)) + tuple(w.shape[2:]), device=dev, dtype=torch.float32)
@@ -173,6 +175,39 @@ class _Head:
         self.p_conv1 = _C(proc.conv1, dev)
         self.p_conv2a = _C(proc.conv2[0], dev)
         last = proc.conv2[2]
+        self.tail_w = _f32(last.weight.reshape(last.weight.shape[0], -1), dev)
+        self.tail_b = _f32(last.bias, dev)
+        self.tail_cout, self.tail_cin = last.weight.shape[0], last.weight.shape[1]
+        self.adaptors = list(head[1].adaptors)
+        self.kinds = [k for a in self.adaptors for k in a.kinds]
+        self.scale = [s for a in self.adaptors for s in a.scale]
+        self.shift = [s for a in self.adaptors for s in a.shift]
+
+
+class _MoGeHead:
+    """Packed MoGeConvParams (modules.py): every convolution as a _Conv, GroupNorm affine vectors in fp32."""
+
+    def __init__(self, head: nn.Sequential, dev, split: bool = False):
+        feat = head[0]
+        pad32 = lambda c: (c + 31) // 32 * 32  # noqa: E731
+        self.dim_proj = feat.dim_proj
+        self.projects = [_Conv(c, dev, split) for c in feat.projects]
+        self.stages = []
+        for blk in feat.upsample_blocks:
+            ct, c3 = blk[0][0], blk[0][1]
+            res = []
+            for rb in list(blk)[1:]:
+                gn1, conv_a, gn2, conv_b = rb.layers[0], rb.layers[2], rb.layers[3], rb.layers[5]
+                res.append(dict(
+                    gn1=(gn1.num_groups, _f32(gn1.weight, dev), _f32(gn1.bias, dev), gn1.eps), a=_Conv(conv_a, dev, split),
+                    gn2=(gn2.num_groups, _f32(gn2.weight, dev), _f32(gn2.bias, dev), gn2.eps), b=_Conv(conv_b, dev, split),
+                    skip=_Conv(rb.skip_connection, dev, split) if isinstance(rb.skip_connection, nn.Conv2d) else None,
+                ))
+            self.stages.append(dict(cin=ct.in_channels - 2, ldc=pad32(ct.in_channels), ct=_Conv(ct, dev, split, cin_pad=pad32(ct.in_channels)), c3=_Conv(c3, dev, split), res=res))
+        ob = feat.output_block[0]
+        self.out_cin, self.out_ldc = ob[0].in_channels - 2, pad32(ob[0].in_channels)
+        self.out_conv = _Conv(ob[0], dev, split, cin_pad=self.out_ldc)
+        last = ob[2]
         self.tail_w = _f32(last.weight.reshape(last.weight.shape[0], -1), dev)
         self.tail_b = _f32(last.bias, dev)
         self.tail_cout, self.tail_cin = last.weight.shape[0], last.weight.shape[1]
@@ -254,7 +289,8 @@ class Engine:
                 raise ValueError("info sharing needs max_num_views >= 2")
         # DPT heads: exact-fp32 MFMA in "parity"; bf16x3 split precision (UFM_BF16X2 activations) in "fast"
         self.head_split = self.numerics in ("fast", "precise", "parity_x3heads")
-        self.heads = {"head1": _Head(m.head1, dev, self.head_split)}
+        moge = not isinstance(m.head1[0], nn.Sequential)  # head_type "moge_conv" (ufm.py:266-267): one feature module, not (DPTFeature, processor)
+        self.heads = {"head1": (_MoGeHead if moge else _Head)(m.head1, dev, self.head_split)}
         if hasattr(m, "uncertainty_head"):
             self.heads["uncertainty_head"] = _Head(m.uncertainty_head, dev, self.head_split)
         self.refine = hasattr(m, "classification_head")
@@ -409,13 +445,13 @@ class Engine:
             assert res_row_mod == 0 and out_row_group == 0 and out.dtype == torch.float32
             hip.conv2d(x, 1, 1, M, lin.k, lin.w, lin.n, 1, 1, 1, 0, out, self.zero, bias=lin.b, act=act, gamma=gamma, res1=res)
 
-    def conv(self, x, B, H, W, c: _Conv, out, *, relu_in=False, act=hip.ACT_NONE, res1=None, res2=None, out_relu=None):
+    def conv(self, x, B, H, W, c: _Conv, out, *, relu_in=False, act=hip.ACT_NONE, res1=None, res2=None, out_relu=None, replicate=False):
         if c.w.dtype == torch.bfloat16:
             hip.conv2d_x3(x, B, H, W, c.cin, c.w, c.cout, c.k, c.k, c.stride, c.pad, out, self.zero, relu_in=relu_in, bias=c.b, act=act, res1=res1, res2=res2, shuffle=c.shuffle, out_relu=out_relu,
-                          passes=getattr(c, "passes", 3))
+                          passes=getattr(c, "passes", 3), replicate=replicate)
         else:
             assert out_relu is None
-            hip.conv2d(x, B, H, W, c.cin, c.w, c.cout, c.k, c.k, c.stride, c.pad, out, self.zero, relu_in=relu_in, bias=c.b, act=act, res1=res1, res2=res2, shuffle=c.shuffle)
+            hip.conv2d(x, B, H, W, c.cin, c.w, c.cout, c.k, c.k, c.stride, c.pad, out, self.zero, relu_in=relu_in, bias=c.b, act=act, res1=res1, res2=res2, shuffle=c.shuffle, replicate=replicate)
 
     def hbuf(self, name: str, shape: Tuple[int, ...]) -> torch.Tensor:
         """Head activation buffer: fp32 [shape] or the split format (2, *shape) bf16."""
@@ -609,6 +645,10 @@ class Engine:
             c2 = self.hbuf(f"{tag}_pc2", (B, H, W, c2a.cout))
             self.conv(up, B, H, W, c2a, c2, act=hip.ACT_RELU)
             hip.head_tail(c2, B * H * W, H * W, hw.tail_cin, hw.tail_w, hw.tail_b, hw.tail_cout, hw.kinds, hw.scale, hw.shift, out, logits)
+        return self._adaptor_outputs(hw, out, logits, B, H, W)
+
+    def _adaptor_outputs(self, hw, out, logits, B: int, H: int, W: int):
+        """Split the decoded channels between the adaptors ([U] AdaptorMap; ufm.py:644-660)."""
         res, c0 = {}, 0
         for a in hw.adaptors:
             n = a.required_channels
@@ -628,6 +668,58 @@ class Engine:
                 res[a.name] = dict(value=raw, logits=logits[:, c0 : c0 + n] if logits is not None else None, kind=a.cls_name)
             c0 += n
         return res
+
+    # ------------------------------------------------------------------ MoGe convolutional head (head_type "moge_conv")
+    def _head_moge(self, hw: _MoGeHead, tag: str, levels: List[torch.Tensor], B: int, gh: int, gw: int, H: int, W: int):
+        """[U] MoGeConvFeature.forward on NHWC maps (oracle/uniception_ref.py::MoGeConvFeature; parity unpinned): per-level
+        1x1 projections summed through the conv kernels' residual input; per stage {copy into a 32-channel-padded buffer +
+        the two view-plane uv channels, ConvTranspose2d(k=s=2) as a pixel-shuffle GEMM, conv3x3 replicate, residual blocks
+        (GroupNorm+ReLU kernel, conv, GroupNorm+ReLU, conv + skip)}; bilinear (align_corners=False) to (H, W) straight into
+        the next concat buffer; conv3x3 replicate + ReLU; the last 1x1 conv + adaptor in ufm_head_tail."""
+        aspect = W / H
+        x = self.hbuf(f"{tag}_proj", (B, gh, gw, hw.dim_proj))
+        for i, c in enumerate(hw.projects):  # torch.stack([...]).sum(dim=1): accumulated in level order
+            self.conv(levels[i], B, gh, gw, c, x, res1=x if i > 0 else None)
+        h, w = gh, gw
+
+        def gn(t, spec, hh, ww, C, name):
+            groups, gw_, gb_, eps = spec
+            o = self.hbuf(name, (B, hh, ww, C))
+            ws = self.buf(f"{tag}_gn_ws", (hip.group_norm_ws_floats(B, 8 * gh * 8 * gw, 64),))
+            hip.group_norm(t, B, hh * ww, C, groups, gw_, gb_, eps, True, o, ws)
+            return o
+
+        for k, st in enumerate(hw.stages):
+            cat = self.hbuf(f"{tag}_cat{k}", (B, h, w, st["ldc"]))
+            hip.resize_nearest(x, B, h, w, st["cin"], cat, h, w, st["ldc"], 0)   # torch.cat([x, uv], dim=1): the x slot
+            hip.fill_uv(cat, B, h, w, st["ldc"], st["cin"], aspect)                 # uv + zero padding to the K chunk
+            co = st["c3"].cout
+            up = self.hbuf(f"{tag}_up{k}", (B, 2 * h, 2 * w, co))
+            self.conv(cat, B, h, w, st["ct"], up)
+            h, w = 2 * h, 2 * w
+            x = self.hbuf(f"{tag}_c3_{k}", (B, h, w, co))
+            self.conv(up, B, h, w, st["c3"], x, replicate=True)
+            for j, rb in enumerate(st["res"]):
+                t = gn(x, rb["gn1"], h, w, rb["a"].cin, f"{tag}_s{k}r{j}_n1")
+                t2 = self.hbuf(f"{tag}_s{k}r{j}_a", (B, h, w, rb["a"].cout))
+                self.conv(t, B, h, w, rb["a"], t2, replicate=True)
+                t3 = gn(t2, rb["gn2"], h, w, rb["b"].cin, f"{tag}_s{k}r{j}_n2")
+                skip = x
+                if rb["skip"] is not None:
+                    skip = self.hbuf(f"{tag}_s{k}r{j}_skip", (B, h, w, rb["b"].cout))
+                    self.conv(x, B, h, w, rb["skip"], skip)
+                o = self.hbuf(f"{tag}_s{k}r{j}_o", (B, h, w, rb["b"].cout))
+                self.conv(t3, B, h, w, rb["b"], o, replicate=True, res1=skip)
+                x = o
+        cat = self.hbuf(f"{tag}_catf", (B, H, W, hw.out_ldc))
+        hip.resize_bilinear(x, B, h, w, hw.out_cin, hw.out_cin, cat, H, W, hw.out_ldc, 0)
+        hip.fill_uv(cat, B, H, W, hw.out_ldc, hw.out_cin, aspect)
+        c = self.hbuf(f"{tag}_outc", (B, H, W, hw.out_conv.cout))
+        self.conv(cat, B, H, W, hw.out_conv, c, act=hip.ACT_RELU, replicate=True)
+        out = torch.empty((B, hw.tail_cout, H, W), device=self.dev, dtype=torch.float32)
+        logits = torch.empty_like(out) if 1 in hw.kinds else None
+        hip.head_tail(c, B * H * W, H * W, hw.tail_cin, hw.tail_w, hw.tail_b, hw.tail_cout, hw.kinds, hw.scale, hw.shift, out, logits)
+        return self._adaptor_outputs(hw, out, logits, B, H, W)
 
     # ------------------------------------------------------------------ UNet fine features (UFM-Refine option)
     def _unet(self, img: torch.Tensor, N: int, H: int, W: int) -> torch.Tensor:
@@ -849,6 +941,12 @@ class Engine:
         dims = [D, Di, Di, Di]
 
         out: Dict[str, Any] = {}
+
+        def run_head(hw, tag):
+            if isinstance(hw, _MoGeHead):
+                return self._head_moge(hw, tag, levels, B, gh, gw, H, W)
+            return self._head(hw, tag, levels, dims, B, gh, gw, H, W)
+
         conc = self.concurrent_heads if self.concurrent_heads is not None else getattr(self._tls, "ns", "") == ""
         if len(self.heads) > 1 and conc and hip.TIMER is None:
             # the heads only share their (read-only) input pyramid: run them on separate HIP streams so the
@@ -861,8 +959,8 @@ class Engine:
             for (tag, hw), st in zip(tags[1:], side_streams):
                 st.wait_stream(main)
                 with torch.cuda.stream(st):
-                    out[tag] = self._head(hw, tag, levels, dims, B, gh, gw, H, W)
-            out[tags[0][0]] = self._head(tags[0][1], tags[0][0], levels, dims, B, gh, gw, H, W)
+                    out[tag] = run_head(hw, tag)
+            out[tags[0][0]] = run_head(tags[0][1], tags[0][0])
             for (tag, _), st in zip(tags[1:], side_streams):
                 main.wait_stream(st)
                 for v in out[tag].values():
@@ -871,7 +969,7 @@ class Engine:
                             t.record_stream(main)
         else:
             for tag, hw in self.heads.items():
-                out[tag] = self._head(hw, tag, levels, dims, B, gh, gw, H, W)
+                out[tag] = run_head(hw, tag)
 
         if self.refine:  # ufm.py:949-1007
             C1 = D + Di

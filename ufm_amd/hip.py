@@ -65,11 +65,14 @@ SIGNATURES = {
     "ufm_maxpool2x2_nhwc": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
     "ufm_resize_nearest_nhwc": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp],
     "ufm_unet_combine": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "ufm_group_norm_nhwc": [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp],
+    "ufm_fill_uv_nhwc": [_vp, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "ufm_resize_bilinear_nhwc": [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp],
     "ufm_pixel_shuffle_planar": [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "ufm_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
     "ufm_add_f32": [_vp, _vp, _vp, _i64, _vp],
 }
-PLAIN = {"ufm_abi_version": (C.c_int, []), "ufm_last_error": (C.c_char_p, []), "ufm_built_arch": (C.c_char_p, [])}
+PLAIN = {"ufm_group_norm_ws_floats": (C.c_int, [C.c_int, C.c_int, C.c_int]), "ufm_abi_version": (C.c_int, []), "ufm_last_error": (C.c_char_p, []), "ufm_built_arch": (C.c_char_p, [])}
 
 
 def lib() -> C.CDLL:
@@ -265,22 +268,22 @@ def cross_attention(q, ldq, k, v, ldkv, out, ldo, B, Nq, Nk, H, scale, fmt):
         raise RuntimeError(f"{name} failed (rc={rc}): {lib().ufm_last_error().decode()}")
 
 
-def conv2d(x, B, H, W, Cin, weight, Cout, KH, KW, stride, pad, out, zero_page, *, relu_in=False, bias=None, act=ACT_NONE, gamma=None, res1=None, res2=None, shuffle=0):
+def conv2d(x, B, H, W, Cin, weight, Cout, KH, KW, stride, pad, out, zero_page, *, relu_in=False, bias=None, act=ACT_NONE, gamma=None, res1=None, res2=None, shuffle=0, replicate=False):
     Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
     _t("ufm_conv2d_nhwc_f32", 2.0 * B * Ho * Wo * Cout * KH * KW * Cin)
     _check(
-        lib().ufm_conv2d_nhwc_f32(_p(x), B, H, W, Cin, _p(weight), Cout, KH, KW, stride, pad, int(relu_in), _p(bias), act, _p(gamma), _p(res1), _p(res2), shuffle, _p(out), 0, _p(zero_page), _stream()),
+        lib().ufm_conv2d_nhwc_f32(_p(x), B, H, W, Cin, _p(weight), Cout, KH, KW, stride, pad, int(relu_in) | (2 if replicate else 0), _p(bias), act, _p(gamma), _p(res1), _p(res2), shuffle, _p(out), 0, _p(zero_page), _stream()),
         "ufm_conv2d_nhwc_f32",
     )
 
 
-def conv2d_x3(x, B, H, W, Cin, weight, Cout, KH, KW, stride, pad, out, zero_page, *, relu_in=False, bias=None, act=ACT_NONE, res1=None, res2=None, shuffle=0, out_relu=None, passes=3):
+def conv2d_x3(x, B, H, W, Cin, weight, Cout, KH, KW, stride, pad, out, zero_page, *, relu_in=False, bias=None, act=ACT_NONE, res1=None, res2=None, shuffle=0, out_relu=None, passes=3, replicate=False):
     """bf16x3 split-precision conv; x / weight / res / out are (2, ...) bf16 tensors (UFM_BF16X2).
     passes=1: the hi planes only (a plain bf16 convolution with fp32 accumulation), same operand and output format."""
     Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
     _t("ufm_conv2d_nhwc_bf16x3" if passes == 3 else "ufm_conv2d_nhwc_bf16x1", 2.0 * B * Ho * Wo * Cout * KH * KW * Cin)
     _check(
-        lib().ufm_conv2d_nhwc_bf16x3(_p(x), B, H, W, Cin, _p(weight), Cout, KH, KW, stride, pad, int(relu_in), _p(bias), act, _p(res1), _p(res2), shuffle, _p(out), _p(out_relu), _p(zero_page), passes, _stream()),
+        lib().ufm_conv2d_nhwc_bf16x3(_p(x), B, H, W, Cin, _p(weight), Cout, KH, KW, stride, pad, int(relu_in) | (2 if replicate else 0), _p(bias), act, _p(res1), _p(res2), shuffle, _p(out), _p(out_relu), _p(zero_page), passes, _stream()),
         "ufm_conv2d_nhwc_bf16x3",
     )
 
@@ -354,6 +357,26 @@ def resize_nearest(x, B, H, W, Cc, out, Ho, Wo, ldc, c_off):
 def unet_combine(cls, unet, N, HW, ldu, w1, b1, w2, b2, method, out):
     _t("ufm_unet_combine", 4.0 * N * HW * 48)
     _check(lib().ufm_unet_combine(_p(cls), _p(unet), _fmt(unet), N, HW, ldu, _p(w1), _p(b1), _p(w2), _p(b2), method, _p(out), _stream()), "ufm_unet_combine")
+
+
+def group_norm(x, B, HW, Cc, groups, weight, bias, eps, relu, out, ws):
+    """nn.GroupNorm(groups, C) (+ ReLU) on an NHWC map (fp32 or split); ws: fp32 workspace of group_norm_ws_floats()."""
+    _t("ufm_group_norm_nhwc", 16.0 * B * HW * Cc)
+    _check(lib().ufm_group_norm_nhwc(_p(x), _fmt(x), B, HW, Cc, Cc, groups, _p(weight), _p(bias), eps, int(relu), _p(out), _p(ws), _stream()), "ufm_group_norm_nhwc")
+
+
+def group_norm_ws_floats(B, HW, groups) -> int:
+    return int(lib().ufm_group_norm_ws_floats(B, HW, groups))
+
+
+def fill_uv(out, B, H, W, ldc, c_off, aspect_ratio):
+    _check(lib().ufm_fill_uv_nhwc(_p(out), _fmt(out), B, H, W, ldc, c_off, float(aspect_ratio), _stream()), "ufm_fill_uv_nhwc")
+
+
+def resize_bilinear(x, B, H, W, Cc, ldi, out, Ho, Wo, ldc, c_off):
+    """F.interpolate(bilinear, align_corners=False) into channels [c_off, c_off + C) of a wider NHWC map."""
+    _t("ufm_resize_bilinear_nhwc", 4.0 * B * Cc * (H * W + Ho * Wo))
+    _check(lib().ufm_resize_bilinear_nhwc(_p(x), _fmt(x), B, H, W, Cc, ldi, _p(out), Ho, Wo, ldc, c_off, _stream()), "ufm_resize_bilinear_nhwc")
 
 
 def pixel_shuffle_planar(x, B, gh, gw, Cc, p, out, split=False):

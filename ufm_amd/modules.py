@@ -318,6 +318,76 @@ class MLPFeatureParams(_Holder):
         self.mlp = _MlpParams(input_feature_dim, int(mlp_ratio * input_feature_dim), output_dim * patch_size * patch_size)
 
 
+class _ResConvBlockParams(_Holder):
+    """[U] MoGe ResidualConvBlock: GroupNorm -> ReLU -> conv3x3 (replicate) -> GroupNorm -> ReLU -> conv3x3 (replicate) + skip.
+    torch modules hold the parameters under the upstream names (layers.0/2/3/5, skip_connection)."""
+
+    def __init__(self, cin: int, cout: int, hidden: int, norm: str = "group_norm"):
+        super().__init__()
+        groups = (lambda ch: max(ch // 32, 1)) if norm == "group_norm" else (lambda ch: 1)
+        self.layers = nn.Sequential(
+            nn.GroupNorm(groups(cin), cin), nn.ReLU(), nn.Conv2d(cin, hidden, 3, padding=1, padding_mode="replicate"),
+            nn.GroupNorm(groups(hidden), hidden), nn.ReLU(), nn.Conv2d(hidden, cout, 3, padding=1, padding_mode="replicate"),
+        )
+        self.skip_connection = nn.Conv2d(cin, cout, 1) if cin != cout else nn.Identity()
+
+
+class MoGeConvParams(_Holder):
+    """``head_type="moge_conv"`` (ufm.py:266-267): parameters of [U] MoGeConvFeature under the upstream attribute names
+    (projects.N, upsample_blocks.K.0.{0,1}, upsample_blocks.K.{1..}.layers.*, output_block.J.*).  The forward pass is
+    Engine._head_moge.  **Parity unpinned** (the class is absent from the reference; oracle/uniception_ref.py restates it)."""
+
+    def __init__(
+        self,
+        input_feature_dims: Union[int, Sequence[int]] = 768,
+        dim_out: Union[int, Sequence[int]] = 2,
+        num_features: int = 4,
+        dim_proj: int = 512,
+        dim_upsample: Sequence[int] = (256, 128, 128),
+        dim_times_res_block_hidden: int = 1,
+        num_res_blocks: int = 1,
+        res_block_norm: str = "group_norm",
+        last_res_blocks: int = 0,
+        last_conv_channels: int = 32,
+        last_conv_size: int = 1,
+        patch_size: int = 14,
+        **_: Any,
+    ):
+        super().__init__()
+        if isinstance(input_feature_dims, int):
+            input_feature_dims = [input_feature_dims] * num_features
+        if isinstance(dim_out, int):
+            dim_out = [dim_out]
+        if len(dim_out) != 1 or last_res_blocks != 0 or last_conv_size != 1:
+            raise NotImplementedError("moge_conv: built for one output block, last_res_blocks=0, last_conv_size=1 (MoGe's defaults)")
+        for c in [dim_proj, last_conv_channels] + list(dim_upsample):
+            if c % 32 != 0:
+                raise NotImplementedError(f"moge_conv: channel count {c} must be a multiple of 32 (conv kernel tiles)")
+        self.patch_size, self.dim_out, self.output_dim = patch_size, list(dim_out), sum(dim_out)
+        self.dim_proj, self.dim_upsample, self.last_conv_channels = dim_proj, list(dim_upsample), last_conv_channels
+        self.projects = nn.ModuleList([nn.Conv2d(c, dim_proj, 1) for c in input_feature_dims])
+        dims_in = [dim_proj] + list(dim_upsample[:-1])
+        self.upsample_blocks = nn.ModuleList(
+            [
+                nn.Sequential(
+                    nn.Sequential(nn.ConvTranspose2d(cin + 2, cout, 2, 2), nn.Conv2d(cout, cout, 3, 1, 1, padding_mode="replicate")),
+                    *[_ResConvBlockParams(cout, cout, dim_times_res_block_hidden * cout, res_block_norm) for _ in range(num_res_blocks)],
+                )
+                for cin, cout in zip(dims_in, dim_upsample)
+            ]
+        )
+        self.output_block = nn.ModuleList(
+            [
+                nn.Sequential(
+                    nn.Conv2d(dim_upsample[-1] + 2, last_conv_channels, 3, 1, 1, padding_mode="replicate"),
+                    nn.ReLU(inplace=True),
+                    nn.Conv2d(last_conv_channels, d, 1, 1, 0, padding_mode="replicate"),
+                )
+                for d in self.dim_out
+            ]
+        )
+
+
 class _DoubleConvParams(_Holder):
     """unet_encoder.py:10-23: parameters of (Conv3x3 pad 1 -> ReLU) x 2 under the reference's names conv.0 / conv.2."""
 
@@ -384,13 +454,18 @@ class AdaptorMap(_Holder):
 
 def make_head(head_type: str, feature_head_kwargs: Dict[str, Any], adaptors_kwargs: Dict[str, Any]) -> nn.Module:
     """ufm.py:243-289 -- Sequential(Sequential(DPTFeature, DPTRegressionProcessor), AdaptorMap(...))."""
-    if head_type != "dpt":
-        raise NotImplementedError(f"head_type {head_type!r}: only 'dpt' is built (moge_conv: SURVEY 8(f) rank 4)")
-    feat = nn.Sequential(DPTFeatureParams(**feature_head_kwargs["dpt_feature"]), DPTProcessorParams(**feature_head_kwargs["dpt_processor"]))
     adaptors = [AdaptorSpec(cfg["class"], **cfg["kwargs"]) for cfg in adaptors_kwargs.values()]
     total = sum(a.required_channels for a in adaptors)
-    if total != feat[1].output_dim:
-        raise ValueError(f"head produces {feat[1].output_dim} channels, adaptors need {total}")
+    if head_type == "moge_conv":
+        feat = MoGeConvParams(**feature_head_kwargs)
+        out_dim = feat.output_dim
+    elif head_type == "dpt":
+        feat = nn.Sequential(DPTFeatureParams(**feature_head_kwargs["dpt_feature"]), DPTProcessorParams(**feature_head_kwargs["dpt_processor"]))
+        out_dim = feat[1].output_dim
+    else:
+        raise ValueError(f"Head type {head_type} not supported.")  # ufm.py:268-269
+    if total != out_dim:
+        raise ValueError(f"head produces {out_dim} channels, adaptors need {total}")
     return nn.Sequential(feat, AdaptorMap(*adaptors))
 
 
