@@ -827,7 +827,7 @@ def test_fill_uv_and_bilinear_resize_into_concat_buffer(hip, fmt):
     hip.fill_uv(out, B, H, W, ldc, C, W / H)
     got = unsplit(out.cpu()) if fmt == "x3" else out.cpu()
     assert (got[..., :C] - want_x).abs().max().item() <= (2e-5 if fmt == "x3" else 2e-6)
-    assert (got[..., C : C + 2] - uv.unsqueeze(0)).abs().max().item() <= 1e-6
+    assert (got[..., C : C + 2] - uv.unsqueeze(0)).abs().max().item() <= (8e-6 if fmt == "x3" else 1e-6)  # (hi, lo) carries 2^-17 relative
     assert got[..., C + 2 :].abs().max().item() == 0.0
 
 
