@@ -8,9 +8,9 @@ lib = hip.lib()
 variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["1", "4"])]
 
 
-def set_variant(v):
-    lib.ufm_debug_set_gemm_flags(4 if v >= 40 else 0)
-    lib.ufm_debug_set_gemm_variant(v - 40 if v >= 40 else v)
+def set_variant(v):  # +80: generic (run-time switched) epilogue instead of the compile-time specialised one
+    lib.ufm_debug_set_gemm_flags(64 if v >= 80 else 4 if v >= 40 else 0)
+    lib.ufm_debug_set_gemm_variant(v - 80 if v >= 80 else v - 40 if v >= 40 else v)
 shapes = [(4096, 4096, 4096, "bf16"), (8192, 8192, 8192, "bf16"), (21904, 3072, 128, "bf16"), (21904, 3072, 128, "f32"), (21904, 3072, 256, "bf16"), (21904, 1024, 128, "res"), (21904, 1024, 128, "f32"),
           (21904, 3072, 1024, "bf16"), (21904, 1024, 1024, "res"), (21904, 4096, 1024, "gelu"), (21904, 1024, 4096, "res"),
           (10952, 3072, 1024, "bf16"), (10952, 1024, 1024, "res"), (10952, 4096, 1024, "gelu"), (10952, 1024, 4096, "res"),
@@ -19,9 +19,11 @@ for M, N, K, mode in shapes:
     A = torch.randn(M, K, device="cuda").bfloat16()
     W = (torch.randn(N, K, device="cuda") * K**-0.5).bfloat16()
     bias = torch.randn(N, device="cuda") * 0.1
+    gamma = (1 + 0.1 * torch.randn(N, device="cuda")) if os.environ.get("GAMMA") == "1" else None
     out = torch.randn(M, N, device="cuda") if mode in ("res", "f32") else torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     def run():
-        hip.gemm_bf16(A, W, M, N, K, out, bias=bias, act=hip.ACT_GELU if mode == "gelu" else hip.ACT_NONE, res=out if mode == "res" else None)
+        hip.gemm_bf16(A, W, M, N, K, out, bias=bias, act=hip.ACT_GELU if mode == "gelu" else hip.ACT_NONE, res=out if mode == "res" else None,
+                      gamma=gamma if mode != "gelu" else None)
     times = {v: [] for v in variants}
     for rnd in range(7):
         for v in variants:

@@ -133,7 +133,7 @@ extern "C" int ufm_debug_set_gemm_tile_rows(int rows) {
     return UFM_OK;
 }
 extern "C" int ufm_debug_set_gemm_flags(int flags) {
-    g_gemm_flags = flags & (2 | 4 | 8 | 16 | 32 | 0xff00);  // 16 / 32: lda / ldw = 0 (every tile reads the same rows: an all-L2-hit probe, tools/lab)
+    g_gemm_flags = flags & (2 | 4 | 8 | 16 | 32 | 64 | 0xff00);  // 64: generic (run-time switched) epilogue in the 8-phase kernels  // 16 / 32: lda / ldw = 0 (every tile reads the same rows: an all-L2-hit probe, tools/lab)
     return UFM_OK;
 }
 
@@ -235,15 +235,24 @@ extern "C" int ufm_gemm_bf16_rope(const uint16_t* A, int lda, const uint16_t* W,
         else
             hipLaunchKernelGGL(gemm_bf16_kernel<0>, grid, block, 0, (hipStream_t)stream, q);
     };
+    // the transformer's hot Linear forms get the epilogue specialised at compile time (gemm_common.h EpiTraits); flag 64 = generic
+    int epi = 0;
+    const bool plain_rows = res_row_mod == 0 && out_row_group == 0 && !rope_cos && !(g_gemm_flags & 64);
+    if (plain_rows && bias && out_dtype == UFM_BF16 && !res && (ldo & 7) == 0 && ((uintptr_t)out & 15) == 0) {
+        if (act == UFM_ACT_GELU && !gamma) epi = 1;
+        else if (act == UFM_ACT_NONE && gamma) epi = 2;
+    } else if (plain_rows && bias && out_dtype == UFM_F32 && res && act == UFM_ACT_NONE) {
+        epi = gamma ? 3 : 4;
+    }
     if (variant == 5) {
         GemmArgs lead = p, rest = p;
         lead.M = m_split;
         rest.m_begin = m_split;
-        ufm_launch_gemm_8ph(lead, out_dtype, (hipStream_t)stream, 8);
-        if (nf_rest) ufm_launch_gemm_8ph(rest, out_dtype, (hipStream_t)stream, nf_rest);
+        ufm_launch_gemm_8ph(lead, out_dtype, (hipStream_t)stream, 8, epi);
+        if (nf_rest) ufm_launch_gemm_8ph(rest, out_dtype, (hipStream_t)stream, nf_rest, epi);
         else launch128(rest);
     } else if (variant == 4) {
-        ufm_launch_gemm_8ph(p, out_dtype, (hipStream_t)stream, nf_lead);
+        ufm_launch_gemm_8ph(p, out_dtype, (hipStream_t)stream, nf_lead, epi);
     } else {
         launch128(p);
     }

@@ -35,7 +35,7 @@ using IC = std::integral_constant<int, K>;
 // of it; its second 64-row half simply has NF - 4 fragments).  Lower tiles make ceil(M / height) * (N / 256) fit whole rounds of
 // the chip where 256-row tiles would strand CUs (M = 10 952, N = 1024: 172 tiles on 256 CUs -> 232 tiles of 192 rows).  The
 // staging, the phase schedule and every output element's accumulation order are those of NF = 8.
-template <int OUT_BF16, int NF>
+template <int OUT_BF16, int NF, int EPI>
 __device__ __forceinline__ void gemm_bf16_8ph_body(const GemmArgs& p, char* smem) {
     static_assert(NF >= 5 && NF <= 8, "NF");
     constexpr int RW = 16 * NF, BMT = 2 * RW;
@@ -202,33 +202,37 @@ __device__ __forceinline__ void gemm_bf16_8ph_body(const GemmArgs& p, char* smem
         if (keep == 123.456f) ((float*)p.out)[0] = keep;
         return;
     }
-    epilogue_lds<OUT_BF16, 64>(p, acc[0], smem + wave * 16384, m0 + wr * RW, n0 + wc * 64, lane);
-    epilogue_lds<OUT_BF16, RW - 64>(p, acc[1], smem + wave * 16384, m0 + wr * RW + 64, n0 + wc * 64, lane);
+    epilogue_lds<OUT_BF16, 64, EPI>(p, acc[0], smem + wave * 16384, m0 + wr * RW, n0 + wc * 64, lane);
+    epilogue_lds<OUT_BF16, RW - 64, EPI>(p, acc[1], smem + wave * 16384, m0 + wr * RW + 64, n0 + wc * 64, lane);
 }
 
-template <int OUT_BF16, int NF>
+template <int OUT_BF16, int NF, int EPI>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_8ph_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[8 * HALF];  // [tile & 1][kind]
-    gemm_bf16_8ph_body<OUT_BF16, NF>(p, smem);
+    gemm_bf16_8ph_body<OUT_BF16, NF, EPI>(p, smem);
 }
 
 }  // namespace
 
-int ufm_launch_gemm_8ph(const GemmArgs& p, int out_dtype, hipStream_t stream, int nf) {
+int ufm_launch_gemm_8ph(const GemmArgs& p, int out_dtype, hipStream_t stream, int nf, int epi) {
     const int bmt = 32 * nf;
     const int ntm = (p.M - p.m_begin + bmt - 1) / bmt, ntn = p.N / 256;
     dim3 grid(ntm * ntn), block(512);
+    // bf16 output: EPI 0 / 1 / 2; fp32 output: EPI 0 / 3 / 4 (gemm_common.h EpiTraits)
+#define UFM_L8E(NF_, OUT_, EPI_) hipLaunchKernelGGL((gemm_bf16_8ph_kernel<OUT_, NF_, EPI_>), grid, block, 0, stream, p)
 #define UFM_L8(NF_)                                                                                   \
     case NF_:                                                                                         \
-        if (out_dtype == UFM_BF16)                                                                    \
-            hipLaunchKernelGGL((gemm_bf16_8ph_kernel<1, NF_>), grid, block, 0, stream, p);            \
-        else                                                                                          \
-            hipLaunchKernelGGL((gemm_bf16_8ph_kernel<0, NF_>), grid, block, 0, stream, p);            \
+        if (out_dtype == UFM_BF16) {                                                                  \
+            if (epi == 1) UFM_L8E(NF_, 1, 1); else if (epi == 2) UFM_L8E(NF_, 1, 2); else UFM_L8E(NF_, 1, 0); \
+        } else {                                                                                      \
+            if (epi == 3) UFM_L8E(NF_, 0, 3); else if (epi == 4) UFM_L8E(NF_, 0, 4); else UFM_L8E(NF_, 0, 0); \
+        }                                                                                             \
         break;
     switch (nf) {
         UFM_L8(5) UFM_L8(6) UFM_L8(7) UFM_L8(8)
         default: return 1;
     }
 #undef UFM_L8
+#undef UFM_L8E
     return 0;
 }

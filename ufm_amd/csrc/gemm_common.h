@@ -77,27 +77,44 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x4 (&acc)[4][4], 
 // instruction moves 4 whole rows: 256-B fp32 / 128-B bf16 contiguous per row, for the residual read
 // (in-place update) and the store alike.  Within a wave LDS ops are in order: no barrier after the writes.
 // ROWS (a multiple of 16, <= 64): only the first ROWS rows of the slice exist (8-phase tiles lower than 256 rows).
-template <int OUT_BF16, int ROWS = 64>
+// EPI: the epilogue's run-time switches as compile-time facts for the transformer's four hot Linear forms (0 = generic, every
+// switch read from the argument block).  With the switches known the unrolled fragment loop has no branches in it, so the
+// compiler interleaves the independent GELU polynomial chains of neighbouring fragments instead of running 32 dependent
+// chains one after the other behind scalar branches and per-column-group `s_waitcnt vmcnt(0)`s:
+//   1 = bias, GELU, bf16 out (fc1)          2 = bias, gamma, bf16 out (QKV with the Q pre-scale)
+//   3 = bias, gamma, fp32 residual in place (proj / fc2 with LayerScale)      4 = bias, fp32 residual in place (no LayerScale)
+template <int EPI>
+struct EpiTraits {
+    static constexpr bool known = EPI != 0;
+    static constexpr bool gelu = EPI == 1, gamma = EPI == 2 || EPI == 3, res = EPI == 3 || EPI == 4;
+};
+
+template <int OUT_BF16, int ROWS = 64, int EPI = 0>
 __device__ __forceinline__ void epilogue_lds(const GemmArgs& p, f32x4 (&acc)[4][4], char* wave_lds, int row0, int col0,
                                              int lane) {
     static_assert(ROWS % 16 == 0 && ROWS > 0 && ROWS <= 64, "ROWS");
+    using E = EpiTraits<EPI>;
+    const bool has_bias = E::known ? true : p.bias != nullptr;
+    const bool has_gamma = E::known ? E::gamma : p.gamma != nullptr;
+    const bool has_res = E::known ? E::res : p.res != nullptr;
+    const int act = E::known ? (E::gelu ? UFM_ACT_GELU : UFM_ACT_NONE) : p.act;
     const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         const int nb = col0 + n * 16 + fq * 4;
         f32x4 bv = {0.f, 0.f, 0.f, 0.f}, gv = {1.f, 1.f, 1.f, 1.f};
-        if (p.bias) bv = *(const f32x4*)(p.bias + nb);
-        if (p.gamma) gv = *(const f32x4*)(p.gamma + nb);
+        if (has_bias) bv = *(const f32x4*)(p.bias + nb);
+        if (has_gamma) gv = *(const f32x4*)(p.gamma + nb);
 #pragma unroll
         for (int m = 0; m < ROWS / 16; ++m) {
             f32x4 v = acc[n][m] + bv;
-            if (p.act == UFM_ACT_GELU && OUT_BF16) {
+            if (act == UFM_ACT_GELU && OUT_BF16) {
                 v = gelu_bf16_x4(v);
-            } else if (p.act != UFM_ACT_NONE) {
+            } else if (act != UFM_ACT_NONE) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act);
+                for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], act);
             }
-            if (p.gamma) v *= gv;
+            if (has_gamma) v *= gv;
             const int r = m * 16 + fr;
             *(f32x4*)(wave_lds + r * 256 + (((n * 4 + fq) ^ (r & 15)) << 4)) = v;
         }
@@ -108,11 +125,11 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& p, f32x4 (&acc)[4][
     // (that serialisation was ~12 us of fixed cost per 5-round GEMM: epilogue time = 11.9 us + bytes / 7.05 TB/s).
     auto readout = [&](auto plain_c) {
         constexpr bool PLAIN = decltype(plain_c)::value;
-        if (OUT_BF16 && !p.res && (p.ldo & 7) == 0 && ((uintptr_t)p.out & 15) == 0) {
+        if (OUT_BF16 && !has_res && (E::known || ((p.ldo & 7) == 0 && ((uintptr_t)p.out & 15) == 0))) {
             // bf16 output without residual: a lane converts 8 consecutive columns (two staged chunks) and stores 16 B,
             // a wave instruction covers 8 whole 128-B row segments
             const int r8 = lane >> 3, c8 = lane & 7;
-            const bool rope = p.rope_cos != nullptr && col0 < p.rope_cols;  // wave-uniform: the wave's 64 columns are one head
+            const bool rope = !E::known && p.rope_cos != nullptr && col0 < p.rope_cols;  // wave-uniform: the wave's 64 columns are one head
 #pragma unroll
             for (int pass = 0; pass < ROWS / 8; ++pass) {
                 const int r = pass * 8 + r8;
@@ -150,7 +167,7 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& p, f32x4 (&acc)[4][
                 if (p.res_row_mod > 0) rrow = row % p.res_row_mod;
                 if (p.out_row_group > 0) orow = (row / p.out_row_group) * (p.out_row_group + 1) + 1 + row % p.out_row_group;
             }
-            if (p.res) v += *(const f32x4*)(p.res + (size_t)rrow * p.ldres + nb);
+            if (has_res) v += *(const f32x4*)(p.res + (size_t)rrow * p.ldres + nb);
             if (OUT_BF16) {
                 u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
                 *(u32x2*)((uint16_t*)p.out + (size_t)orow * p.ldo + nb) = pk;
@@ -159,7 +176,7 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& p, f32x4 (&acc)[4][
             }
         }
     };
-    if (row0 + ROWS <= p.M && p.res_row_mod == 0 && p.out_row_group == 0)
+    if (row0 + ROWS <= p.M && (E::known || (p.res_row_mod == 0 && p.out_row_group == 0)))
         readout(std::integral_constant<bool, true>{});
     else
         readout(std::integral_constant<bool, false>{});
@@ -176,4 +193,5 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // gemm_bf16_8ph.hip: 256x256 8-phase kernel (N % 256 == 0, K >= 128, 32-bit operand offsets)
 // nf = 16-row fragments per wave (5..8): tile height 32 * nf rows
-int ufm_launch_gemm_8ph(const GemmArgs& p, int out_dtype, hipStream_t stream, int nf = 8);
+// epi: EpiTraits code the host has verified against the argument block (0 = generic)
+int ufm_launch_gemm_8ph(const GemmArgs& p, int out_dtype, hipStream_t stream, int nf = 8, int epi = 0);
