@@ -950,7 +950,9 @@ def test_conv2d_single_pass_is_a_bf16_convolution(hip, B, H, W, Cin, Cout, k, st
         (3, 23, 17, 32, 512, 1, 1, 0, False, 0, 1, 0),    # 1x1, Cin = 32: a single K-tile, below the 8-phase kernel's minimum -> falls back
         (3, 23, 17, 64, 512, 1, 1, 0, False, 0, 1, 0),    # 1x1, nt = 2 (prologue only + tail waits)
         (2, 9, 11, 96, 1024, 1, 1, 0, False, 0, 0, 2),    # ConvTranspose (pixel-shuffle store), Co = 256
-        (8, 148, 148, 32, 256, 3, 1, 1, True, 0, 1, 0),   # 685 tiles: auto = 2 whole rounds on the 8-phase kernel + 128-row rest
+        (8, 148, 148, 32, 256, 3, 1, 1, True, 0, 1, 0),   # 685 tiles, 9 K-tiles: auto = the 128-row kernels (fewer than 16 K-tiles)
+        (4, 148, 148, 64, 256, 3, 1, 1, True, 0, 1, 0),   # 343 tiles, 18 K-tiles: auto = 1 whole round on the 8-phase kernel + 128-row rest (87 tiles < half a round)
+        (5, 148, 148, 64, 256, 3, 1, 1, False, 0, 0, 0),  # 428 tiles: the last partial round (172 tiles >= half the chip) stays on the 8-phase kernel
         (2, 19, 19, 768, 256, 3, 1, 1, False, 0, 0, 0),   # 46 blocks of 64x64, 216 K-tiles: the deep ring incl. its drain
         (3, 41, 37, 64, 128, 3, 1, 1, True, 0, 1, 0),     # Cout = 128: the 512 px x 128 cout 8-phase layout (ragged M = 4551)
         (2, 30, 30, 96, 384, 3, 2, 1, False, 2, 0, 0),    # Cout = 384 = 3 x 128: three column tiles of the 512 x 128 layout, stride 2

@@ -244,10 +244,15 @@ static void launch_conv_x3(const ConvX3Args& p, int passes, hipStream_t stream) 
         launch128(p);
     } else if (ok8 && g_conv_variant == 2) {
         ufm_launch_conv_x3_8ph(p, stream);
-    } else if (ok8 && g_conv_variant == 0 && t8 >= 256) {  // (variants 1 and 3 never take this branch)
-        const long long full = t8 / 256;                                // whole rounds of the 8-phase kernel
-        const long long m_main = full * 256 / (Cout / tile_n) * tile_m;  // leading pixels whose tiles fit in them
-        if (m_main >= M || full == 0) {
+    } else if (ok8 && g_conv_variant == 0 && t8 >= ufm_device_cu_count() / 2 && KH * KW * (Cin / 32) >= 16) {  // (variants 1 and 3 never take this branch)
+        // Measured per shape (tools/lab/conv_rounds.py, profiles/r03/conv_rounds.log): a last partial round of at least half
+        // the chip is cheaper on the 8-phase kernel than on the 128-row kernels (148^2 RCU, 684 tiles: 485 vs 518 us; 74^2 RCU,
+        // 171 tiles: 154 vs 178 us), a smaller one on the 128-row kernels (148^2 at 4 images, 342 tiles: 270 vs 301 us); with
+        // fewer than 16 K-tiles (1x1 layers) the 8-phase prologue and drain cost more than its loop gains (110 vs 122-130 us).
+        const long long ncu = ufm_device_cu_count();
+        const long long full = t8 / ncu;                                 // whole rounds of the 8-phase kernel
+        const long long m_main = full * ncu / (Cout / tile_n) * tile_m;  // leading pixels whose tiles fit in them
+        if (m_main >= M || t8 - full * ncu >= ncu / 2) {
             ufm_launch_conv_x3_8ph(p, stream);
         } else {
             ConvX3Args lead = p, rest = p;
