@@ -28,6 +28,7 @@ Rank 0 prints ONE JSON line.  Extra objects:
 """
 
 import argparse
+import glob
 import json
 import os
 import sys
@@ -294,15 +295,18 @@ def main():
         # summary of `tools/pmc_traffic.sh` (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc passes over
         # this same command), averaged over the launches of the family like `achieved`.
         pmc, traffic_src = {}, None
-        pmc_path = os.path.join(ROOT, "profiles", "r02", "pmc_step_summary.json")
+        # the newest committed summary (profiles/rNN/pmc_step_summary.json): a round's counters are regenerated on its final tree
+        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_step_summary.json")))
+        pmc_path = pmc_files[-1] if pmc_files else os.path.join(ROOT, "profiles", "r03", "pmc_step_summary.json")
+        pmc_rel = os.path.relpath(pmc_path, ROOT)
         if os.path.exists(pmc_path) and B == 8 and res == 518 and args.numerics == "fast":
             cand = json.load(open(pmc_path))
             meta = cand.get("_meta", {})
             # counters measured on other kernel sources are not evidence for this run: drop them (traffic = null)
             if meta.get("csrc_sha256") == csrc_sha256():
-                pmc, traffic_src = cand, {"file": "profiles/r02/pmc_step_summary.json", "csrc_sha256": meta["csrc_sha256"], "commit": meta.get("commit_at_summarise_time")}
+                pmc, traffic_src = cand, {"file": pmc_rel, "csrc_sha256": meta["csrc_sha256"], "commit": meta.get("commit_at_summarise_time")}
             else:
-                traffic_src = {"file": "profiles/r02/pmc_step_summary.json", "stale": True, "measured_on_csrc_sha256": meta.get("csrc_sha256"), "this_tree": csrc_sha256()}
+                traffic_src = {"file": pmc_rel, "stale": True, "measured_on_csrc_sha256": meta.get("csrc_sha256"), "this_tree": csrc_sha256()}
         for k, v in kernels.items():
             if k in pmc and "hbm_bytes_per_step" in pmc[k]:
                 v["traffic"] = pmc[k]["hbm_bytes_per_step"] / v["launches"]  # per C-ABI call, like `achieved`

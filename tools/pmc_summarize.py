@@ -4,7 +4,7 @@ per-launch HBM bytes (FETCH_SIZE is in KiB and is doubled: on gfx950 it reports 
 coalesced reads -- MI355X_MICROARCH.md section HBM; WRITE_SIZE is exact for 16-B stores), MFMA-busy fraction, LDS
 bank-conflict cycles."""
 import collections, csv, glob, hashlib, json, os, subprocess, sys
-out_path = sys.argv[1] if len(sys.argv) > 1 else "profiles/r02/pmc_step_summary.json"
+out_path = sys.argv[1] if len(sys.argv) > 1 else "profiles/r03/pmc_step_summary.json"
 
 
 def csrc_sha256(root):
