@@ -91,40 +91,82 @@ __global__ __launch_bounds__(256, 2) void dpt_tail_fused_kernel(TailFusedArgs p)
     const int ybase = (int)(p.sy * max(ty0 - 1, 0));
     const int ytop = min(p.h - 1, (int)(p.sy * min(ty0 + TS, p.H - 1)) + 1);
     const int nrows = ytop - ybase + 1;
+    // Stage-A work items of this thread: item k = (source row r, halo column hx, 8-channel group c8) with index tid + 256 k
+    // (nrows * 72 <= 936 of them: at most AK = 4 per thread).  Their geometry does not depend on the pass, only the channel
+    // offset does, so it is computed once; the 16 global loads of a pass are issued TOGETHER and one pass AHEAD (right
+    // before the previous pass's tap loop), so their latency runs under 216 MFMAs instead of being exposed once per item
+    // (the un-pipelined loop waited vmcnt(0) behind every item's four loads: ~16 exposed L2/HBM latencies per block).
+    constexpr int AK = (TROWS * HS * 4 + 255) / 256;
+    size_t a_src0[AK], a_src1[AK];
+    int a_dst[AK];
+    float a_lx1[AK];
+    bool a_ok[AK];
+#pragma unroll
+    for (int k = 0; k < AK; ++k) {
+        const int u = tid + 256 * k;
+        const int r = u / (HS * 4), rem = u - r * (HS * 4);
+        const int hx = rem >> 2, c8 = rem & 3;
+        const int ox = tx0 - 1 + hx;
+        a_ok[k] = u < nrows * (HS * 4) && (unsigned)ox < (unsigned)p.W;  // columns outside the image are never read
+        const float fx = p.sx * ox;
+        const int x0 = a_ok[k] ? (int)fx : 0;
+        const int x1 = x0 + (x0 < p.w - 1 ? 1 : 0);
+        a_lx1[k] = fx - x0;
+        const size_t row = ((size_t)b * p.h + min(ybase + r, p.h - 1)) * p.w;
+        a_src0[k] = (row + x0) * CIN + c8 * 8;
+        a_src1[k] = (row + x1) * CIN + c8 * 8;
+        a_dst[k] = (r * HS + hx) * 32 + c8 * 8;
+    }
+    u32x4 ald[AK][4];  // [item][x0 hi, x0 lo, x1 hi, x1 lo]
+    auto issue_a = [&](int q) {
+#pragma unroll
+        for (int k = 0; k < AK; ++k) {
+            if (a_ok[k]) {
+                const uint16_t* s0 = p.in + a_src0[k] + q * CQ;
+                const uint16_t* s1 = p.in + a_src1[k] + q * CQ;
+                ald[k][0] = *(const u32x4*)s0;
+                ald[k][1] = *(const u32x4*)(s0 + p.in_plane);
+                ald[k][2] = *(const u32x4*)s1;
+                ald[k][3] = *(const u32x4*)(s1 + p.in_plane);
+            }
+        }
+    };
+    issue_a(0);
     for (int q = 0; q < CIN / CQ; ++q) {
         if (q) __syncthreads();  // every wave is done reading the previous pass's tile and weights
-        u32x4 wreg[9];           // this pass's weights: loaded now, parked in LDS after the fill (latency under the fill)
-#pragma unroll
-        for (int it = 0; it < 9; ++it) wreg[it] = *(const u32x4*)(w_src + it * CIN + q * CQ);
         // ---- fill, separable.  Stage A: T[r][hx] = lx0 * v[y][x0] + lx1 * v[y][x1] for the <= 13 source rows y the tile
         // touches and its 18 halo columns (fp32, parked in the weight region, which is idle until the fill is done).
         // Stage B: halo[hy][hx] = split(ly0 * T[r0][hx] + ly1 * T[r1][hx]).  Same operations in the same order as the
         // one-step form ly0 * (lx0 v00 + lx1 v01) + ly1 * (lx0 v10 + lx1 v11), so the result is bit-identical, with
         // 2.8x fewer global loads and ~1/3 less VALU work (each horizontal lerp is shared by ~1.75 output rows). ----
         float* T = (float*)(smem + HALO_B);
-        for (int u = tid; u < nrows * (HS * 4); u += 256) {
-            const int r = u / (HS * 4), rem = u - r * (HS * 4);
-            const int hx = rem >> 2, c8 = rem & 3;
-            const int ox = tx0 - 1 + hx;
-            if ((unsigned)ox >= (unsigned)p.W) continue;  // never read
-            const float fx = p.sx * ox;
-            const int x0 = (int)fx;
-            const int x1 = x0 + (x0 < p.w - 1 ? 1 : 0);
-            const float lx1 = fx - x0, lx0 = 1.f - lx1;
-            const uint16_t* src = p.in + ((size_t)b * p.h + (ybase + r)) * p.w * CIN + q * CQ + c8 * 8;
+#pragma unroll
+        for (int k = 0; k < AK; ++k) {
+            if (!a_ok[k]) continue;
             float v0[8], v1[8];
-            ld_split8(src + (size_t)x0 * CIN, p.in_plane, v0);
-            ld_split8(src + (size_t)x1 * CIN, p.in_plane, v1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {  // (= ld_split8)
+                v0[2 * j] = __uint_as_float(ald[k][0][j] << 16) + __uint_as_float(ald[k][1][j] << 16);
+                v0[2 * j + 1] = __uint_as_float(ald[k][0][j] & 0xffff0000u) + __uint_as_float(ald[k][1][j] & 0xffff0000u);
+                v1[2 * j] = __uint_as_float(ald[k][2][j] << 16) + __uint_as_float(ald[k][3][j] << 16);
+                v1[2 * j + 1] = __uint_as_float(ald[k][2][j] & 0xffff0000u) + __uint_as_float(ald[k][3][j] & 0xffff0000u);
+            }
+            const float lx1 = a_lx1[k], lx0 = 1.f - lx1;
             f32x4 t0, t1;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                t0[k] = lx0 * v0[k] + lx1 * v1[k];
-                t1[k] = lx0 * v0[4 + k] + lx1 * v1[4 + k];
+            for (int j = 0; j < 4; ++j) {
+                t0[j] = lx0 * v0[j] + lx1 * v1[j];
+                t1[j] = lx0 * v0[4 + j] + lx1 * v1[4 + j];
             }
-            float* dst = T + (r * HS + hx) * 32 + c8 * 8;
+            float* dst = T + a_dst[k];
             *(f32x4*)dst = t0;
             *(f32x4*)(dst + 4) = t1;
         }
+        // this pass's weights: requested now, parked in LDS after stage B (their latency runs under stage B, which only
+        // touches LDS); not earlier, so that they are never live beside the 64 registers of stage-A loads
+        u32x4 wreg[9];
+#pragma unroll
+        for (int it = 0; it < 9; ++it) wreg[it] = *(const u32x4*)(w_src + it * CIN + q * CQ);
         __syncthreads();
         for (int u = tid; u < NPX * 4; u += 256) {
             const int px = u >> 2, c8 = u & 3;
@@ -160,6 +202,7 @@ __global__ __launch_bounds__(256, 2) void dpt_tail_fused_kernel(TailFusedArgs p)
 #pragma unroll
         for (int it = 0; it < 9; ++it) *(u32x4*)(w_dst + it * 4096) = wreg[it];
         __syncthreads();
+        if (q + 1 < CIN / CQ) issue_a(q + 1);  // the next pass's stage-A loads fly under this pass's tap loop
         // ---- mma: 9 taps of this 32-channel chunk ----
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
