@@ -296,7 +296,10 @@ int ufm_dpt_tail_fused(const uint16_t* in, int B, int h, int w, int Cin, const u
  *     covariance [B][3][HW] = (xx, yy, xy) with rho = 0.99 tanh(r); inverse covariance [B][3][HW]; log-determinant [B][1][HW]
  *     (-> UFMFlowFieldOutput.flow_covariance / _inv / _log_det, ufm.py:648-651).
  *   ConfidenceAdaptor (keypoint_confidence, ufm.py:653-654): type 0 = min(vmin + exp(x), vmax), 1 = (vmax-vmin) sigmoid(x) + vmin,
- *     2 = identity. */
+ *     2 = identity.
+ * PARITY UNPINNED: both formulas are restated from the published adaptor semantics -- the defining uniception source is absent
+ * from the reference and no fixture there holds their outputs; only the un-map / rescale applied afterwards
+ * (base.py:295-319) is pinned by reference-generated goldens. */
 int ufm_adaptor_covariance2d(const float* raw, int B, int HW, float* cov, float* inv_cov, float* log_det, void* stream);
 int ufm_adaptor_confidence(const float* raw, int64_t n, int type, float vmin, float vmax, float* out, void* stream);
 
