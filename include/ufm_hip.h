@@ -154,6 +154,11 @@ int ufm_warp_bilinear(const void* target, int tgt_dtype, int Ht, int Wt, const f
 int ufm_layernorm(const float* x, int ldx, const int32_t* row_index, int rows_out, int D,
                   const float* weight, const float* bias, float eps, void* out, int out_dtype,
                   int ldo, void* stream);
+/* The same, writing a row slice of a larger UFM_BF16X2 buffer: the lo plane is out_plane elements behind the hi plane
+ * (>= rows_out*ldo; ignored for the other output types). */
+int ufm_layernorm_slice(const float* x, int ldx, const int32_t* row_index, int rows_out, int D,
+                        const float* weight, const float* bias, float eps, void* out, int out_dtype,
+                        int ldo, long long out_plane, void* stream);
 
 /* Residual update fused in front of the LayerNorm:  x[r, :] += gamma[:] * branch[r, :]  (fp32 math; branch = the bf16
  * output of the preceding Attention.proj / Mlp.fc2 Linear, gamma = LayerScale or NULL), x is written back, then
@@ -247,7 +252,7 @@ int ufm_conv2d_nhwc_bf16x3(const uint16_t* in, int B, int H, int W, int Cin, con
  *
  * ufm_gemm_bf16x3: out[M][N] = epilogue(A[M][K] . W[N][K]^T), every product hi*hi + hi*lo + lo*hi, fp32 accumulate.
  *   A: UFM_BF16X2 [2][M][K] (ufm_layernorm / ufm_attention_bf16x3 / a previous ufm_gemm_bf16x3 write it);
- *   W: UFM_BF16X2 [2][N][K], pre-split at pack time.   v = acc + bias[n]; v = act(v) (exact erf GELU); v *= gamma[n];
+ *   W: UFM_BF16X2 [2][N][K], pre-split at pack time.   v = acc + bias[n]; v = act(v) (GELU: branch-free erf, |err| <= 1.5e-7); v *= gamma[n];
  *   out_dtype UFM_BF16X2: out = split(v) as [2][M][N];   out_dtype UFM_F32: v += res[m][n] (fp32, may be NULL, may alias
  *   out: the fp32 residual stream is updated in place), out[m][n] = v.
  *   Requirements: K % 32 == 0, N % 32 == 0, 16-byte aligned pointers.  zero_page: >= 128 B of zeros (device).

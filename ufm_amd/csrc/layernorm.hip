@@ -25,6 +25,7 @@ struct LnAdd {  // ADD: x[row] += gamma * branch[row] before the statistics (row
     const uint16_t* branch;  // bf16 [rows][ldb]
     const float* gamma;      // fp32 [D] or null (= 1)
     int ldb;
+    long long out_plane;     // UFM_BF16X2 output: element offset of the lo plane (rows_out * ldo unless the output is a row slice of a larger buffer)
 };
 
 __device__ __forceinline__ f32x4 ln_add4(const f32x4& x, const uint16_t* br, const float* gamma, int c4) {
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel_fixed(const float* __res
             u32x2 pl = {pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3])};
             uint16_t* o = (uint16_t*)out + (size_t)row * ldo + c * 4;
             *(u32x2*)o = ph;
-            *(u32x2*)(o + (size_t)rows_out * ldo) = pl;
+            *(u32x2*)(o + add.out_plane) = pl;
         } else if (OUT_BF16 == 1) {
             u32x2 pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
             *(u32x2*)((uint16_t*)out + (size_t)row * ldo + c * 4) = pk;
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                 u32x2 pl = {pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3])};
                 uint16_t* o = (uint16_t*)out + (size_t)row * ldo + c * 4;
                 *(u32x2*)o = ph;
-                *(u32x2*)(o + (size_t)rows_out * ldo) = pl;
+                *(u32x2*)(o + add.out_plane) = pl;
             } else if (OUT_BF16 == 1) {
                 u32x2 pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
                 *(u32x2*)((uint16_t*)out + (size_t)row * ldo + c * 4) = pk;
@@ -221,8 +222,24 @@ extern "C" int ufm_layernorm(const float* x, int ldx, const int32_t* row_index, 
     UFM_REQUIRE(D % 4 == 0 && D <= MAX_VPL * 256 && D > 0, "ufm_layernorm: D=%d must be a multiple of 4 and <= %d", D, MAX_VPL * 256);
     UFM_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && ldx >= D && ldo >= D, "ufm_layernorm: bad ldx/ldo %d/%d", ldx, ldo);
     UFM_REQUIRE(out_dtype == UFM_F32 || out_dtype == UFM_BF16 || out_dtype == UFM_BF16X2, "ufm_layernorm: bad out_dtype");
-    launch_layernorm<false>(x, ldx, row_index, rows_out, D, weight, bias, eps, out, out_dtype, ldo, LnAdd{nullptr, nullptr, 0}, (hipStream_t)stream);
+    launch_layernorm<false>(x, ldx, row_index, rows_out, D, weight, bias, eps, out, out_dtype, ldo, LnAdd{nullptr, nullptr, 0, (long long)rows_out * ldo}, (hipStream_t)stream);
     UFM_CHECK_LAUNCH("ufm_layernorm");
+    return UFM_OK;
+}
+
+// ufm_layernorm writing a ROW SLICE of a larger (2, rows_total, ldo) split buffer: the lo plane sits out_plane elements behind
+// the hi plane (engine: the micro-batch streams' pyramid levels land directly in the full-batch buffer the heads read)
+extern "C" int ufm_layernorm_slice(const float* x, int ldx, const int32_t* row_index, int rows_out, int D,
+                                   const float* weight, const float* bias, float eps, void* out, int out_dtype,
+                                   int ldo, long long out_plane, void* stream) {
+    UFM_REQUIRE(x && weight && bias && out, "ufm_layernorm_slice: null pointer");
+    UFM_REQUIRE(rows_out > 0, "ufm_layernorm_slice: rows_out=%d", rows_out);
+    UFM_REQUIRE(D % 4 == 0 && D <= MAX_VPL * 256 && D > 0, "ufm_layernorm_slice: D=%d must be a multiple of 4 and <= %d", D, MAX_VPL * 256);
+    UFM_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && ldx >= D && ldo >= D, "ufm_layernorm_slice: bad ldx/ldo %d/%d", ldx, ldo);
+    UFM_REQUIRE(out_dtype == UFM_F32 || out_dtype == UFM_BF16 || out_dtype == UFM_BF16X2, "ufm_layernorm_slice: bad out_dtype");
+    UFM_REQUIRE(out_dtype != UFM_BF16X2 || (out_plane >= (long long)rows_out * ldo && out_plane % 4 == 0), "ufm_layernorm_slice: out_plane=%lld must be >= rows_out * ldo and a multiple of 4", out_plane);
+    launch_layernorm<false>(x, ldx, row_index, rows_out, D, weight, bias, eps, out, out_dtype, ldo, LnAdd{nullptr, nullptr, 0, out_plane}, (hipStream_t)stream);
+    UFM_CHECK_LAUNCH("ufm_layernorm_slice");
     return UFM_OK;
 }
 
@@ -235,7 +252,7 @@ extern "C" int ufm_add_layernorm(float* x, int ldx, const uint16_t* branch, int 
     UFM_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && ldb % 4 == 0 && ldx >= D && ldo >= D && ldb >= D, "ufm_add_layernorm: bad ldx/ldb/ldo %d/%d/%d", ldx, ldb, ldo);
     UFM_REQUIRE(((uintptr_t)branch % 8) == 0 && ((uintptr_t)x % 16) == 0, "ufm_add_layernorm: misaligned pointer");
     UFM_REQUIRE(out_dtype == UFM_F32 || out_dtype == UFM_BF16 || out_dtype == UFM_BF16X2, "ufm_add_layernorm: bad out_dtype");
-    launch_layernorm<true>(x, ldx, nullptr, rows, D, weight, bias, eps, out, out_dtype, ldo, LnAdd{branch, gamma, ldb}, (hipStream_t)stream);
+    launch_layernorm<true>(x, ldx, nullptr, rows, D, weight, bias, eps, out, out_dtype, ldo, LnAdd{branch, gamma, ldb, (long long)rows * ldo}, (hipStream_t)stream);
     UFM_CHECK_LAUNCH("ufm_add_layernorm");
     return UFM_OK;
 }

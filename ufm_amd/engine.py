@@ -232,6 +232,11 @@ class Engine:
         self._packed_key = None
         self._tls = threading.local()  # .ns = workspace namespace of the micro-batch this thread is running
         self.micro_batches = 2  # >1: the batch is split into micro-batches that run concurrently on separate HIP streams
+        # joint_heads: the micro-batch streams run the TRUNK only (patchify .. info sharing: GEMM / attention launches whose
+        # partial rounds and HBM-bound epilogues overlap across streams); their view-1 feature pyramids land in one
+        # full-batch buffer and the DPT heads run ONCE on the whole batch (full-size convolution launches: a 148^2 RCU layer
+        # at 8 images is 485 us against 2 x 270 us at 4 + 4), the two heads on two streams.  Same arithmetic per pair.
+        self.joint_heads = True
         self._streams: List[torch.cuda.Stream] = []
         # "fast", optional: the residual stream's fp32 read-modify-write is done by the next LayerNorm launch
         # (ufm_add_layernorm) instead of the proj / fc2 GEMM epilogues.  Measured (tools/lab/ab_engine.py, interleaved, same
@@ -460,7 +465,15 @@ class Engine:
         return self.buf(name, shape)
 
     def level_ln(self, x, D, row_index, rows, w, b, name: str) -> torch.Tensor:
-        """LayerNorm + row gather into a head-format feature level."""
+        """LayerNorm + row gather into a head-format feature level.  With joint heads the micro-batch's rows go straight
+        into their slice of the full-batch level buffer (``_tls.joint`` = (buffers by name, first row, total rows))."""
+        joint = getattr(self._tls, "joint", None)
+        if joint is not None:
+            bufs, row0, rows_total = joint
+            full = bufs[name]  # (2, rows_total, D) split planes or (rows_total, D) fp32
+            dst = full.narrow(-2, row0, rows)
+            hip.layernorm(x, D, row_index, rows, D, w, b, 1e-6, dst, split=self.head_split, out_plane=rows_total * D)
+            return dst
         t = self.hbuf(name, (rows, D))
         hip.layernorm(x, D, row_index, rows, D, w, b, 1e-6, t, split=self.head_split)
         return t
@@ -791,12 +804,25 @@ class Engine:
         results: List[Any] = [None] * nmb
         errors: List[BaseException] = []
 
+        joint = self.joint_heads and not self.refine
+        Np_ = gh * gw
+        shared: List[torch.Tensor] = []
+        if joint:  # full-batch pyramid buffers (main namespace); micro-batch i fills rows [bounds[i] * Np, bounds[i+1] * Np)
+            self._tls.ns = ""
+            shared = [self.hbuf(f"lvl_joint{k}", (B * Np_, d)) for k, d in enumerate([self.D, self.Di, self.Di, self.Di])]
+            by_name = dict(zip(("lvl0", "lvl_i0", "lvl_i1", "lvl3"), shared))
+
         def work(i: int):
             try:
                 with torch.cuda.device(self.dev), torch.cuda.stream(self._streams[i]):
                     self._tls.ns = f"mb{i}/"
                     lo, hi = bounds[i], bounds[i + 1]
-                    results[i] = self._forward_images(src[lo:hi], tgt[lo:hi], layout, scale3, shift3, H, W, Hs, Ws, Ht, Wt)
+                    self._tls.joint = (by_name, lo * Np_, B * Np_) if joint else None  # level_ln writes its rows in place
+                    try:
+                        r = self._forward_images(src[lo:hi], tgt[lo:hi], layout, scale3, shift3, H, W, Hs, Ws, Ht, Wt, levels_only=joint)
+                    finally:
+                        self._tls.joint = None
+                    results[i] = None if joint else r
             except BaseException as exc:  # surfaced on the caller's thread
                 errors.append(exc)
 
@@ -812,6 +838,9 @@ class Engine:
             cur.wait_stream(s)
         if errors:
             raise errors[0]
+        if joint:
+            self._tls.ns = ""
+            return self._heads_and_refine(shared, [self.D, self.Di, self.Di, self.Di], B, H, W)
         return self._merge(results)
 
     def _merge(self, parts: List[Dict[str, Any]]) -> Dict[str, Any]:
@@ -839,7 +868,7 @@ class Engine:
                 out[tag] = {name: {k: cat([p[tag][name][k] for p in parts]) for k in parts[0][tag][name]} for name in parts[0][tag]}
         return out
 
-    def _forward_images(self, src, tgt, layout, scale3, shift3, H, W, Hs, Ws, Ht, Wt, symmetrized: bool = False) -> Dict[str, Any]:
+    def _forward_images(self, src, tgt, layout, scale3, shift3, H, W, Hs, Ws, Ht, Wt, symmetrized: bool = False, levels_only: bool = False):
         B = src.shape[0]
         gh, gw = H // self.P, W // self.P
         Np = gh * gw
@@ -866,9 +895,9 @@ class Engine:
                 hip.patchify(rs, 1, B, H, W, self.P, [1.0, 1.0, 1.0], [0.0, 0.0, 0.0], dst, KPAD)
                 if want_unet:
                     hip.image_to_nhwc(rs, 1, B, H, W, [1.0, 1.0, 1.0], [0.0, 0.0, 0.0], unet_imgs[v], 32)
-        return self._forward_patches(patches, B, H, W, unet_imgs, symmetrized)
+        return self._forward_patches(patches, B, H, W, unet_imgs, symmetrized, levels_only)
 
-    def _forward_patches(self, patches, B: int, H: int, W: int, unet_imgs: Optional[List[torch.Tensor]] = None, symmetrized: bool = False) -> Dict[str, Any]:
+    def _forward_patches(self, patches, B: int, H: int, W: int, unet_imgs: Optional[List[torch.Tensor]] = None, symmetrized: bool = False, levels_only: bool = False):
         B2 = 2 * B
         gh, gw = H // self.P, W // self.P
         n_enc = B if symmetrized else B2  # images that go through the encoder
@@ -939,7 +968,19 @@ class Engine:
         lvl3 = self.level_ln(y, Di, info_v1, B * Np, inw, inb, "lvl3")
         levels = [lvl0, inter[0], inter[1], lvl3]  # ufm.py:603-608 (view-1 pyramid only; view 2's is never decoded)
         dims = [D, Di, Di, Di]
+        if levels_only:  # joint_heads: the caller runs the heads on the whole batch
+            return levels
+        return self._heads_and_refine(levels, dims, B, H, W, y, enc_first, (info_v1, info_v2, info_all), unet_imgs)
 
+    def _heads_and_refine(self, levels, dims, B: int, H: int, W: int, y=None, enc_first=None, info_tabs=None, unet_imgs=None) -> Dict[str, Any]:
+        """The prediction heads on the view-1 pyramid (ufm.py:637-660) and, for UFM-Refine, the classification features +
+        local refinement (ufm.py:949-1007; needs the trunk's residual stream ``y`` and ``enc_first``)."""
+        B2 = 2 * B
+        gh, gw = H // self.P, W // self.P
+        Np = gh * gw
+        D, Di = self.D, self.Di
+        inw, inb = self.info_norm
+        info_v1, info_v2, info_all = info_tabs if info_tabs is not None else (None, None, None)
         out: Dict[str, Any] = {}
 
         def run_head(hw, tag):

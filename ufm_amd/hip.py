@@ -44,6 +44,7 @@ SIGNATURES = {
     "ufm_warp_bilinear": [_vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _f, _vp, _vp],
     "ufm_dpt_tail_fused": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "ufm_layernorm": [_vp, _i, _vp, _i, _i, _vp, _vp, _f, _vp, _i, _i, _vp],
+    "ufm_layernorm_slice": [_vp, _i, _vp, _i, _i, _vp, _vp, _f, _vp, _i, _i, _i64, _vp],
     "ufm_add_layernorm": [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _f, _vp, _i, _i, _vp],
     "ufm_fill_rows": [_vp, _i, _i, _i, _vp, _i, _vp],
     "ufm_add_rows": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp],
@@ -204,9 +205,13 @@ def gemm_bf16(A, W, M, N, K, out, *, bias=None, act=ACT_NONE, gamma=None, res=No
     )
 
 
-def layernorm(x, ldx, row_index, rows_out, D, weight, bias, eps, out, ldo=None, split=False):
-    """split=True: `out` is a (2, rows_out, D) bf16 tensor in the UFM_BF16X2 format."""
+def layernorm(x, ldx, row_index, rows_out, D, weight, bias, eps, out, ldo=None, split=False, out_plane=None):
+    """split=True: `out` is a (2, rows_out, D) bf16 tensor in the UFM_BF16X2 format.  out_plane (elements): `out` is a row
+    slice of a larger split buffer whose planes are that far apart (ufm_layernorm_slice)."""
     _t("ufm_layernorm", rows_out * D * (4.0 + (4 if split else out.element_size())))
+    if out_plane is not None:
+        _check(lib().ufm_layernorm_slice(_p(x), ldx, _p(row_index), rows_out, D, _p(weight), _p(bias), eps, _p(out), BF16X2 if split else _dt(out), ldo or D, int(out_plane), _stream()), "ufm_layernorm_slice")
+        return
     _check(lib().ufm_layernorm(_p(x), ldx, _p(row_index), rows_out, D, _p(weight), _p(bias), eps, _p(out), BF16X2 if split else _dt(out), ldo or D, _stream()), "ufm_layernorm")
 
 
