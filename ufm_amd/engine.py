@@ -590,6 +590,8 @@ class Engine:
 
     # ------------------------------------------------------------------ DPT head
     def _head(self, hw: _Head, tag: str, levels: List[torch.Tensor], level_dims: List[int], B: int, gh: int, gw: int, H: int, W: int):
+        # (Measured in round 3 and not kept: the four level chains on four HIP streams -- 37.8 vs 37.1 ms per step at B = 8,
+        #  and a nested stream fork inside the two-stream head capture crashed hipGraph capture at B = 1.)
         Fd = hw.feature_dim
         ld = hw.layer_dims
         sizes = [(4 * gh, 4 * gw), (2 * gh, 2 * gw), (gh, gw), ((gh - 1) // 2 + 1, (gw - 1) // 2 + 1)]
