@@ -93,6 +93,13 @@ def test_gemm_8phase_bitwise_equals_128_kernel_repeated(hip, M, N, K):
         hip.gemm_bf16(A, W, M, N, K, want, bias=bias, res=res)
         want_b = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
         hip.gemm_bf16(A, W, M, N, K, want_b, bias=bias, act=1)
+        # the other two compile-time epilogue forms of the 8-phase kernel (gemm_common.h EpiTraits 2 and 3): bias + per-column
+        # scale -> bf16 (QKV with the Q pre-scale), bias + LayerScale + fp32 residual (proj / fc2)
+        gamma = (1.0 + rnd(N, seed=7, scale=0.2)).to(DEV)
+        want_g = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+        hip.gemm_bf16(A, W, M, N, K, want_g, bias=bias, gamma=gamma)
+        want_gr = torch.zeros(M, N, device=DEV)
+        hip.gemm_bf16(A, W, M, N, K, want_gr, bias=bias, gamma=gamma, res=res)
         # (variant, pinned tile rows): the 8-phase kernel at its four tile heights (160 / 192 / 224 rows skip the MFMA
         # fragments past the tile's end; ragged last tiles at every height), the hybrid split and the cost model's own pick
         for rep in range(3):
@@ -105,6 +112,13 @@ def test_gemm_8phase_bitwise_equals_128_kernel_repeated(hip, M, N, K):
                 got_b = torch.full((M, N), 3.0, device=DEV, dtype=torch.bfloat16)
                 hip.gemm_bf16(A, W, M, N, K, got_b, bias=bias, act=1)
                 assert torch.equal(got_b.view(torch.int16), want_b.view(torch.int16)), (variant, rows, rep)
+                if rep == 0:
+                    got_g = torch.full((M, N), 3.0, device=DEV, dtype=torch.bfloat16)
+                    hip.gemm_bf16(A, W, M, N, K, got_g, bias=bias, gamma=gamma)
+                    assert torch.equal(got_g.view(torch.int16), want_g.view(torch.int16)), (variant, rows, "bias+gamma -> bf16")
+                    got_gr = torch.full((M, N), 3.0, device=DEV)
+                    hip.gemm_bf16(A, W, M, N, K, got_gr, bias=bias, gamma=gamma, res=res)
+                    assert torch.equal(got_gr, want_gr), (variant, rows, "bias+gamma+residual")
     finally:
         lib.ufm_debug_set_gemm_variant(0)
         lib.ufm_debug_set_gemm_tile_rows(0)
