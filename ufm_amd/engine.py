@@ -466,10 +466,10 @@ class Engine:
 
     def level_ln(self, x, D, row_index, rows, w, b, name: str) -> torch.Tensor:
         """LayerNorm + row gather into a head-format feature level.  With joint heads the micro-batch's rows go straight
-        into their slice of the full-batch level buffer (``_tls.joint`` = (buffers by name, first row, total rows))."""
+        into their slice of the full-batch level buffer (``_tls.joint``: level buffers by name, first row, total rows)."""
         joint = getattr(self._tls, "joint", None)
         if joint is not None:
-            bufs, row0, rows_total = joint
+            bufs, row0, rows_total = joint["levels"], joint["row0"], joint["rows_total"]
             full = bufs[name]  # (2, rows_total, D) split planes or (rows_total, D) fp32
             dst = full.narrow(-2, row0, rows)
             hip.layernorm(x, D, row_index, rows, D, w, b, 1e-6, dst, split=self.head_split, out_plane=rows_total * D)
@@ -806,20 +806,30 @@ class Engine:
         results: List[Any] = [None] * nmb
         errors: List[BaseException] = []
 
-        joint = self.joint_heads and not self.refine
+        # (UFM-Refine keeps per-micro-batch heads with UNet fine features -- its UNet input maps are built per micro-batch --
+        #  and with the cross-attention variant, whose residual stream is view-major: a micro-batch is not a row slice of it)
+        joint = self.joint_heads and not (self.refine and (self.unet is not None or self.info_cross))
         Np_ = gh * gw
         shared: List[torch.Tensor] = []
+        y_full = enc_first_full = None
         if joint:  # full-batch pyramid buffers (main namespace); micro-batch i fills rows [bounds[i] * Np, bounds[i+1] * Np)
             self._tls.ns = ""
             shared = [self.hbuf(f"lvl_joint{k}", (B * Np_, d)) for k, d in enumerate([self.D, self.Di, self.Di, self.Di])]
             by_name = dict(zip(("lvl0", "lvl_i0", "lvl_i1", "lvl3"), shared))
+            if self.refine:  # the classification head also reads the info-sharing residual stream and the first encoder level
+                self._index_tables(B, Np_)  # the full-batch row tables, built before the workers start
+                y_full = self.buf("info_x_joint", (B * 2 * Np_, self.Di))
+                enc_first_full = (self.buf("cls_in_x2", (2, 2 * B * Np_, self.D + self.Di), torch.bfloat16) if self.head_split
+                                  else self.buf("enc_first", (2 * B * Np_, self.D)))
 
         def work(i: int):
             try:
                 with torch.cuda.device(self.dev), torch.cuda.stream(self._streams[i]):
                     self._tls.ns = f"mb{i}/"
                     lo, hi = bounds[i], bounds[i + 1]
-                    self._tls.joint = (by_name, lo * Np_, B * Np_) if joint else None  # level_ln writes its rows in place
+                    # level_ln (and, for UFM-Refine, the residual stream / first encoder level) write their rows in place
+                    self._tls.joint = dict(levels=by_name, row0=lo * Np_, rows_total=B * Np_, y=y_full, enc_first=enc_first_full,
+                                           pair0=lo, pairs_total=B) if joint else None
                     try:
                         r = self._forward_images(src[lo:hi], tgt[lo:hi], layout, scale3, shift3, H, W, Hs, Ws, Ht, Wt, levels_only=joint)
                     finally:
@@ -842,7 +852,11 @@ class Engine:
             raise errors[0]
         if joint:
             self._tls.ns = ""
-            return self._heads_and_refine(shared, [self.D, self.Di, self.Di, self.Di], B, H, W)
+            tabs = None
+            if self.refine:
+                ix = self._index_tables(B, Np_)
+                tabs = (ix["info_v1"], ix["info_v2"], ix["info_all"])
+            return self._heads_and_refine(shared, [self.D, self.Di, self.Di, self.Di], B, H, W, y_full, enc_first_full, tabs)
         return self._merge(results)
 
     def _merge(self, parts: List[Dict[str, Any]]) -> Dict[str, Any]:
@@ -915,9 +929,22 @@ class Engine:
         # cross-attention variant (view, pair, patch) -- one view's tokens of the whole batch contiguous
         enc_info_rows = idx["enc_all"] if self.info_cross else idx["enc_info"]
 
+        jt = getattr(self._tls, "joint", None)
+
         def on_enc(i, xx):
             nonlocal enc_first, lvl0
-            if self.refine and i == self.enc_indices[0]:
+            if self.refine and i == self.enc_indices[0] and jt is not None and jt["enc_first"] is not None:
+                # joint heads: this micro-batch's view-1 / view-2 rows of the full-batch buffer ([view-1 batch | view-2 batch])
+                full, Bt, p0 = jt["enc_first"], jt["pairs_total"], jt["pair0"]
+                ld = full.shape[-1]
+                for v, tab in enumerate((idx["enc_v1"], idx["enc_all"][B * Np :])):
+                    dst = full.narrow(-2, (v * Bt + p0) * Np, B * Np)
+                    if self.head_split:
+                        hip.layernorm(xx, D, tab, B * Np, D, nw, nb, 1e-6, dst[0], ldo=ld, split=True, out_plane=2 * Bt * Np * ld)
+                    else:
+                        hip.layernorm(xx, D, tab, B * Np, D, nw, nb, 1e-6, dst)
+                enc_first = full
+            elif self.refine and i == self.enc_indices[0]:
                 if self.head_split:  # straight into the classification head's split-format input, columns [0, D)
                     enc_first = self.buf("cls_in_x2", (2, B2 * Np, D + Di), torch.bfloat16)
                     hip.layernorm(xx, D, idx["enc_all"], B2 * Np, D, nw, nb, 1e-6, enc_first[0], ldo=D + Di, split=True)
@@ -933,7 +960,10 @@ class Engine:
 
         # ---- info sharing ----
         M2 = B * 2 * Np
-        y = self.buf("info_x", (M2, Di))
+        if jt is not None and jt["y"] is not None:  # joint heads (UFM-Refine): this micro-batch's rows of the full-batch stream
+            y = jt["y"].narrow(0, jt["pair0"] * 2 * Np, M2)
+        else:
+            y = self.buf("info_x", (M2, Di))
         vpe = None if self.info_cross else self._view_pe_table(Np)
         if self.info_proj is None:
             src32 = enc_info if enc_info.dtype == torch.float32 else None
