@@ -26,3 +26,9 @@ cfg = ufm_amd.ufm_refine_config(use_unet_feature=True) if hasattr(ufm_amd, "ufm_
 if cfg is not None:
     r = ufm_amd.UniFlowMatchClassificationRefinement(**cfg).eval(); init_weights_(r, 0); r = r.to("cuda")
     soak(r, 4, "UFM-Refine+UNet B=4 fast")
+    del r
+r = ufm_amd.UniFlowMatchClassificationRefinement(**ufm_amd.ufm_refine_config()).eval(); init_weights_(r, 0); r = r.to("cuda")
+soak(r, 8, "UFM-Refine B=8 fast (joint heads)")
+del r
+m = ufm_amd.UniFlowMatchConfidence(**ufm_amd.ufm_base_config()).eval(); init_weights_(m, 0); m = m.to("cuda").set_numerics("precise")
+soak(m, 8, "UFM-Base B=8 precise")
