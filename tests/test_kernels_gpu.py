@@ -1092,6 +1092,31 @@ def test_split_format_layernorm_upsample_tail(hip):
     assert (ot.cpu()[:, 0] - y[:, 0]).abs().max() <= 2e-4 and (ot.cpu()[:, 1] - torch.sigmoid(y[:, 1])).abs().max() <= 1e-4
 
 
+@pytest.mark.parametrize("split", [True, False])
+def test_layernorm_slice_writes_only_its_rows_of_a_larger_buffer(hip, split):
+    """ufm_layernorm_slice (engine: the micro-batch streams' pyramid levels land in one full-batch buffer): rows [r0, r0 + n)
+    of a (2, R, D) split buffer -- lo plane R*D elements behind the hi plane -- or of a plain (R, D) one equal the stand-alone
+    LayerNorm bit for bit and every other row keeps its fill value."""
+    R, D, r0, n = 50, 256, 13, 21
+    x = rnd(n, D, seed=1, scale=3.0).to(DEV)
+    w, b = (1 + rnd(D, seed=2, scale=0.1)).to(DEV), rnd(D, seed=3, scale=0.1).to(DEV)
+    if split:
+        want = torch.zeros(2, n, D, device=DEV, dtype=torch.bfloat16)
+        hip.layernorm(x, D, None, n, D, w, b, 1e-6, want, split=True)
+        full = torch.full((2, R, D), 7.0, device=DEV, dtype=torch.bfloat16)
+        dst = full.narrow(-2, r0, n)
+        hip.layernorm(x, D, None, n, D, w, b, 1e-6, dst, split=True, out_plane=R * D)
+        assert torch.equal(full[:, r0 : r0 + n].view(torch.int16), want.view(torch.int16))
+        assert torch.all(full[:, :r0] == 7.0) and torch.all(full[:, r0 + n :] == 7.0)
+    else:
+        want = torch.zeros(n, D, device=DEV)
+        hip.layernorm(x, D, None, n, D, w, b, 1e-6, want)
+        full = torch.full((R, D), 7.0, device=DEV)
+        hip.layernorm(x, D, None, n, D, w, b, 1e-6, full.narrow(0, r0, n), out_plane=R * D)
+        assert torch.equal(full[r0 : r0 + n], want)
+        assert torch.all(full[:r0] == 7.0) and torch.all(full[r0 + n :] == 7.0)
+
+
 # ----------------------------------------------------------------------------- UNet layout kernels (R5)
 def to_fmt(x_nhwc, split):
     """fp32 NHWC -> device buffer in the head format (fp32, or the (2, ...) bf16 split planes)."""

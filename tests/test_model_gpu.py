@@ -568,6 +568,29 @@ def test_two_stream_micro_batches_are_repeatable_at_benchmark_batch(env):
         assert torch.equal(one.covisibility.mask[0], wm[i]), i
 
 
+@pytest.mark.parametrize("refine", [False, True])
+def test_joint_heads_are_bitwise_the_per_micro_batch_heads(env, refine):
+    """engine.joint_heads (round 3): the two micro-batch streams run the trunk only, write their pyramid levels (and, for
+    UFM-Refine, the residual stream and the first encoder level) into full-batch buffers, and the heads run once on the whole
+    batch.  Same arithmetic per pair: outputs equal the per-micro-batch heads bit for bit, at the benchmark shape."""
+    ufm_amd, _ = env
+    from ufm_amd.modules import init_weights_
+
+    if refine:
+        model = ufm_amd.UniFlowMatchClassificationRefinement(**ufm_amd.ufm_refine_config(resolution_wh=(518, 518))).eval()
+    else:
+        model = ufm_amd.UniFlowMatchConfidence(**ufm_amd.ufm_base_config()).eval()
+    init_weights_(model, seed=0)
+    model = model.to(DEV).set_numerics("fast")
+    src, tgt = u8((5, 518, 518, 3), 31).to(DEV), u8((5, 518, 518, 3), 32).to(DEV)  # micro-batches of 2 and 3 pairs
+    outs = []
+    for joint in (False, True):
+        model.engine().joint_heads = joint
+        o = model.predict_correspondences_batched(src, tgt)
+        outs.append((o.flow.flow_output.clone(), o.covisibility.mask.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_concurrent_heads_are_bitwise_the_serial_heads(env):
     """A single-stream forward runs the flow and the covisibility DPT head on two HIP streams (engine default for batches
     that are not split into micro-batches); the heads share only their read-only input pyramid, so the result must be
