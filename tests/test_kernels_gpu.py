@@ -78,6 +78,35 @@ def test_gemm_bf16(hip, M, N, K, act, use_gamma, use_res, out_bf16, row_mod, row
     assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("M,N,K", [(2740, 1024, 4096), (2738, 768, 768), (1370, 1024, 320), (700, 3072, 1024)])
+def test_gemm_128_two_k_tiles_per_barrier_is_bit_identical(hip, M, N, K):
+    """Grids of at most one block per CU (the one-pair shapes) run the 128x128 kernel with two K-tiles per barrier
+    (gemm_bf16.hip KS = 2, 128 KiB of LDS): same MFMA sequence per accumulator, so it must equal the one-tile-per-barrier
+    form (flag 128) bit for bit -- even K-tile counts, an odd one (K = 320: 5 tiles, the last group half full), all four
+    epilogue forms' outputs (fp32 residual, bf16 GELU)."""
+    lib = hip.lib()
+    A = bf16r(rnd(M, K, seed=1)).to(DEV).bfloat16()
+    W = bf16r(rnd(N, K, seed=2, scale=K**-0.5)).to(DEV).bfloat16()
+    bias, res = rnd(N, seed=3, scale=0.1).to(DEV), rnd(M, N, seed=5).to(DEV)
+    outs = {}
+    try:
+        lib.ufm_debug_set_gemm_variant(1)
+        for flag in (128, 0):
+            lib.ufm_debug_set_gemm_flags(flag)
+            f = torch.full((M, N), 3.0, device=DEV)
+            hip.gemm_bf16(A, W, M, N, K, f, bias=bias, res=res)
+            g = torch.full((M, N), 3.0, device=DEV, dtype=torch.bfloat16)
+            hip.gemm_bf16(A, W, M, N, K, g, bias=bias, act=1)
+            outs[flag] = (f, g)
+    finally:
+        lib.ufm_debug_set_gemm_variant(0)
+        lib.ufm_debug_set_gemm_flags(0)
+    assert torch.equal(outs[0][0], outs[128][0])
+    assert torch.equal(outs[0][1].view(torch.int16), outs[128][1].view(torch.int16))
+    ref = A.float() @ W.float().T + bias + res
+    assert (outs[0][0] - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("M,N,K", [(256 * 9 + 77, 1024, 128), (256 * 7, 1024, 192), (5000, 2304, 768), (4 * 1370, 1024, 4096), (300, 256, 1024), (8 * 1369, 768, 768)])
 def test_gemm_8phase_bitwise_equals_128_kernel_repeated(hip, M, N, K):
     """Race screen for the counted-vmcnt schedule: the 8-phase kernel (variant 4) and the hybrid split (5) accumulate in

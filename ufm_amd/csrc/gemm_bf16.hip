@@ -14,9 +14,14 @@
 
 namespace {
 
-template <int OUT_BF16>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+// KS = K-tiles per barrier.  KS = 1: two 32-KiB stages, two co-resident blocks per CU (they hide each other's DMA waits).
+// KS = 2 (grids of at most one block per CU -- the one-pair shapes): a lone block spends a K-step on its own serial chain
+// {vmcnt(0), barrier, LDS reads, 32 MFMAs} (~0.75 us against 0.24 us of MFMA issue), so it takes two K-tiles per barrier:
+// half the barriers, twice the MFMAs behind each (128 KiB of LDS).  Every accumulator sees the same MFMA sequence in the
+// same K order as with KS = 1: results are bit-identical.
+template <int OUT_BF16, int KS = 1>
+__global__ __launch_bounds__(256, KS == 1 ? 2 : 1) void gemm_bf16_kernel(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * KS * STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntn = p.N / BN, ntm = (p.M - p.m_begin + BM - 1) / BM;
     // XCD chunking + grouped rasterization: 64 consecutive logical tiles (what one XCD runs at a time) cover
@@ -71,26 +76,36 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
+    // buffer of K-tile kt: group (kt / KS) & 1, slot kt % KS
+    auto buf_of = [](int kt) { return ((kt / KS) & 1) * KS + kt % KS; };
+#pragma unroll
+    for (int j = 0; j < KS; ++j)
+        if (j < nk) stage(buf_of(j), j);
+    for (int kt = 0; kt < nk; kt += KS) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-        const char* s = smem + (kt & 1) * STAGE_BYTES;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int coff = ((kk * 4 + fq) ^ sw) * 16;
-            bf16x8 a[4], b[4];
+        for (int j = 0; j < KS; ++j)
+            if (kt + KS + j < nk) stage(buf_of(kt + KS + j), kt + KS + j);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] = *(const bf16x8*)(s + a_off[i] + coff);
-                b[i] = *(const bf16x8*)(s + b_off[i] + coff);
+        for (int j = 0; j < KS; ++j) {
+            if (KS > 1 && kt + j >= nk) break;
+            const char* s = smem + buf_of(kt + j) * STAGE_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int coff = ((kk * 4 + fq) ^ sw) * 16;
+                bf16x8 a[4], b[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    a[i] = *(const bf16x8*)(s + a_off[i] + coff);
+                    b[i] = *(const bf16x8*)(s + b_off[i] + coff);
+                }
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[n], a[m], acc[n][m], 0, 0, 0);
             }
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[n], a[m], acc[n][m], 0, 0, 0);
         }
     }
 
@@ -133,7 +148,7 @@ extern "C" int ufm_debug_set_gemm_tile_rows(int rows) {
     return UFM_OK;
 }
 extern "C" int ufm_debug_set_gemm_flags(int flags) {
-    g_gemm_flags = flags & (2 | 4 | 8 | 16 | 32 | 64 | 0xff00);  // 64: generic (run-time switched) epilogue in the 8-phase kernels  // 16 / 32: lda / ldw = 0 (every tile reads the same rows: an all-L2-hit probe, tools/lab)
+    g_gemm_flags = flags & (2 | 4 | 8 | 16 | 32 | 64 | 128 | 0xff00);  // 128: never the two-K-tiles-per-barrier form of the 128x128 kernel  // 64: generic (run-time switched) epilogue in the 8-phase kernels  // 16 / 32: lda / ldw = 0 (every tile reads the same rows: an all-L2-hit probe, tools/lab)
     return UFM_OK;
 }
 
@@ -230,10 +245,15 @@ extern "C" int ufm_gemm_bf16_rope(const uint16_t* A, int lda, const uint16_t* W,
     auto launch128 = [&](const GemmArgs& q) {
         const int ntm = (q.M - q.m_begin + BM - 1) / BM, ntn128 = N / BN;
         dim3 grid(ntm * ntn128), block(256);
-        if (out_dtype == UFM_BF16)
-            hipLaunchKernelGGL(gemm_bf16_kernel<1>, grid, block, 0, (hipStream_t)stream, q);
-        else
-            hipLaunchKernelGGL(gemm_bf16_kernel<0>, grid, block, 0, (hipStream_t)stream, q);
+        // at most one block per CU anyway: two K-tiles per barrier (bit-identical; g_gemm_flags & 128 = never, for A/B)
+        const bool lone = (int)grid.x <= NCU && K >= 4 * BK && !(g_gemm_flags & 128);
+        if (out_dtype == UFM_BF16) {
+            if (lone) hipLaunchKernelGGL((gemm_bf16_kernel<1, 2>), grid, block, 0, (hipStream_t)stream, q);
+            else hipLaunchKernelGGL((gemm_bf16_kernel<1, 1>), grid, block, 0, (hipStream_t)stream, q);
+        } else {
+            if (lone) hipLaunchKernelGGL((gemm_bf16_kernel<0, 2>), grid, block, 0, (hipStream_t)stream, q);
+            else hipLaunchKernelGGL((gemm_bf16_kernel<0, 1>), grid, block, 0, (hipStream_t)stream, q);
+        }
     };
     // the transformer's hot Linear forms get the epilogue specialised at compile time (gemm_common.h EpiTraits); flag 64 = generic
     int epi = 0;
