@@ -143,3 +143,139 @@ def test_a_failing_rank_poisons_the_gather_instead_of_blocking_the_others(world,
         ranks, cause = got
         assert ranks == [fail_rank]
         assert cause == ("ValueError" if r == fail_rank else None)  # the local exception is chained on its own rank
+
+
+def _failing_paths_worker(rank, world, port, n_pairs, fail_rank, path, ret):
+    """The failing step is never consumed through result(): the failure has to surface -- on EVERY rank, at the same call --
+    from wait() (bench.py's path) or from the slot reuse inside submit(), before anybody enters a further collective."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ufm_amd.dist import ShardedPredictor, ShardFailed
+
+    g = torch.Generator().manual_seed(0)
+    src = torch.randint(0, 256, (n_pairs, 6, 5, 3), dtype=torch.uint8, generator=g)
+    tgt = torch.randint(0, 256, (n_pairs, 6, 5, 3), dtype=torch.uint8, generator=g)
+    calls = [0]
+
+    def predict(s, t):
+        calls[0] += 1
+        if rank == fail_rank and calls[0] == 2:
+            raise ValueError("boom")
+        return _fake_predict(s, t)
+
+    sp = ShardedPredictor(predict, depth=2)
+    raised_at, ranks = None, None
+    try:
+        t0 = sp.submit(src, tgt)
+        t1 = sp.submit(src, tgt)  # fails on fail_rank, joins the gather poisoned
+        if path == "wait":
+            sp.wait(t0)           # healthy step
+            raised_at = "wait"
+            sp.wait(t1)           # default check=True: every rank raises here
+            raised_at = None
+        else:
+            sp.wait(t0, check=False)
+            sp.wait(t1, check=False)  # pure waits: nobody has looked at the flags yet
+            t2 = sp.submit(src, tgt)  # reuses slot of t0 (healthy, unchecked so far)
+            raised_at = "submit"
+            sp.submit(src, tgt)       # reuses the slot of t1: every rank raises here, before the new all_gather
+            raised_at = None
+    except ShardFailed as exc:
+        ranks = list(exc.ranks)
+    # after the collective failure every rank is at the same point: a further step works
+    t = sp.submit(src, tgt)
+    f, m = sp.result(t)
+    rf, rm = _fake_predict(src, tgt)
+    sp.drain()
+    ret[rank] = (raised_at, ranks, bool(torch.equal(f, rf) and torch.equal(m, rm)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("path", ["wait", "submit"])
+def test_failure_is_collective_on_the_wait_and_slot_reuse_paths(path):
+    world, fail_rank = 3, 1
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_paths_worker, args=(r, world, port, 6, fail_rank, path, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0  # in particular: no rank hung in an all_gather the failing rank never joined
+    for r in range(world):
+        raised_at, ranks, ok_after = ret[r]
+        assert raised_at == path and ranks == [fail_rank], (r, raised_at, ranks)
+        assert ok_after, r
+
+
+def _tagging_predict(src, tgt):
+    """Stub predict for the config-3 partition test: every output pixel carries the pair's id (channel 0 of pixel (0,0) of the
+    source holds it) and a step tag (from the target), so global order and ring reuse are visible in the gathered result."""
+    pid = src[:, 0, 0, 0].float()
+    step = tgt[:, 0, 0, 0].float()
+    b, h, w = src.shape[0], src.shape[1], src.shape[2]
+    flow = torch.stack([pid.view(b, 1, 1).expand(b, h, w), step.view(b, 1, 1).expand(b, h, w)], dim=1).contiguous()
+    mask = (pid * 0.5 + step).view(b, 1, 1).expand(b, h, w).contiguous()
+    return flow, mask
+
+
+def _config3_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ufm_amd.dist import ShardedPredictor, ShardFailed, shard_bounds
+
+    n_pairs, steps = 64, 7
+    src = torch.zeros(n_pairs, 4, 4, 3, dtype=torch.uint8)
+    src[:, 0, 0, 0] = torch.arange(n_pairs, dtype=torch.uint8)
+    seen = []
+
+    def predict(s, t):
+        seen.append((int(s[0, 0, 0, 0]), int(s.shape[0]), int(t[0, 0, 0, 0])))
+        if int(t[0, 0, 0, 0]) == 5 and rank == 6:  # step 5 fails on rank 6 only
+            raise RuntimeError("rank 6 lost its GPU")
+        return _tagging_predict(s, t)
+
+    sp = ShardedPredictor(predict, depth=2)
+    ok, failed_steps, last = True, [], None
+    for step in range(steps):
+        tgt = torch.full((n_pairs, 4, 4, 3), step, dtype=torch.uint8)
+        tk = sp.submit(src, tgt)
+        if last is not None:  # bench.py's loop: consume the previous step while this one's gather is in flight
+            try:
+                f, m = sp.result(last[0])
+                ok = ok and bool((f[:, 0, 0, 0] == torch.arange(n_pairs)).all()) and bool((f[:, 1] == last[1]).all()) \
+                    and bool(torch.equal(m[:, 0, 0], torch.arange(n_pairs) * 0.5 + last[1]))
+            except ShardFailed as exc:
+                failed_steps.append((last[1], list(exc.ranks)))
+        last = (tk, step)
+    f, m = sp.result(last[0])
+    ok = ok and bool((f[:, 0, 0, 0] == torch.arange(n_pairs)).all()) and bool((f[:, 1] == last[1]).all())
+    sp.drain()
+    lo, hi = shard_bounds(n_pairs, rank, world)
+    ret[rank] = (ok, failed_steps, seen, lo, hi)
+    dist.destroy_process_group()
+
+
+def test_config3_partition_64_pairs_over_8_ranks_ring_of_two_seven_steps():
+    """BASELINE config 3's exact split (B = 64 over 8 ranks, 8 pairs each; /root/reference/uniflowmatch/models/ufm.py:308-315 is why
+    the split is legal) on 8 gloo ranks: global order of the gathered pairs, reuse of the two-deep ring over 7 steps, every
+    rank computing exactly its contiguous 8 pairs, and one rank failing at step 5 -- seen by all ranks for that step only."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_config3_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    for r in range(world):
+        ok, failed_steps, seen, lo, hi = ret[r]
+        assert (lo, hi) == (8 * r, 8 * r + 8)
+        assert ok, r
+        assert failed_steps == [(5, [6])], (r, failed_steps)
+        assert seen == [(8 * r, 8, s) for s in range(7)], (r, seen)  # its own contiguous shard, every step, in order

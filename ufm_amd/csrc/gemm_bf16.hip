@@ -148,7 +148,7 @@ extern "C" int ufm_debug_set_gemm_tile_rows(int rows) {
     return UFM_OK;
 }
 extern "C" int ufm_debug_set_gemm_flags(int flags) {
-    g_gemm_flags = flags & (2 | 4 | 8 | 16 | 32 | 64 | 128 | 0xff00);  // 128: never the two-K-tiles-per-barrier form of the 128x128 kernel  // 64: generic (run-time switched) epilogue in the 8-phase kernels  // 16 / 32: lda / ldw = 0 (every tile reads the same rows: an all-L2-hit probe, tools/lab)
+    g_gemm_flags = flags & (2 | 4 | 8 | 16 | 32 | 64 | 128 | 0xff00 | 0x70000);  // 0x70000: start stagger of the 8-phase kernel's first round (lab)  // 128: never the two-K-tiles-per-barrier form of the 128x128 kernel  // 64: generic (run-time switched) epilogue in the 8-phase kernels  // 16 / 32: lda / ldw = 0 (every tile reads the same rows: an all-L2-hit probe, tools/lab)
     return UFM_OK;
 }
 

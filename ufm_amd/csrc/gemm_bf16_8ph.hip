@@ -52,6 +52,12 @@ __device__ __forceinline__ void gemm_bf16_8ph_body(const GemmArgs& p, char* smem
     const int gm = min(GM, ntm - grp * GM);
     const int m0 = p.m_begin + (grp * GM + in_g % gm) * BMT, n0 = (in_g / gm) << 8;
     const int nt = p.K >> 6;
+    if (p.debug & 0x70000) {  // lab (tools/lab/epi_contention.py): first-round blocks start (block / 8) % 4 x units x ~1 us apart
+        if (blockIdx.x < 256) {
+            const int units = ((p.debug >> 16) & 7) * (int)((blockIdx.x >> 3) & 3);
+            for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(32);
+        }
+    }
 
     // ---- DMA source offsets (elements).  Wave w issues pieces w and 8+w of every half-tile; piece = 8 rows ----
     const int srow = lane >> 3, slot = lane & 7;

@@ -62,9 +62,16 @@ class ShardedPredictor:
     result into ring slot ``i % depth``; ``result(i)`` waits for that gather and returns ``(flow, mask)`` of ALL
     pairs in global order.  A slot is reused ``depth`` submits later (its gather is waited for first).
     A rank whose shard is empty (fewer pairs than ranks) skips ``predict`` and contributes a zero pad, so no rank
-    ever misses the collective.  A rank whose ``predict`` RAISES still joins the collective: its pad carries a poison
-    flag (one extra fp32 row per rank), every rank sees it once the gather completes, and ``result`` / ``wait`` /
-    ``drain`` raise ``ShardFailed`` on all of them -- nobody is left blocked in the all_gather until it times out."""
+    ever misses the collective.
+
+    Failure is collective on EVERY path.  A rank whose ``predict`` RAISES still joins the collective: its pad carries
+    a poison flag (one extra fp32 row per rank).  The gathered flag rows are identical on all ranks, and every path
+    that retires a slot -- ``result``, ``wait`` (``check=True`` is the default), ``drain`` and the slot reuse inside
+    ``submit`` -- reads them, so all ranks raise ``ShardFailed`` for the same ticket at the same point of their
+    (identical) call sequences, BEFORE any of them enters a further collective: nobody is left blocked in an
+    all_gather until it times out.  On a GPU the flag rows are copied to pinned host memory by a side stream right
+    behind the gather, so reading them ``depth`` submits later costs an (already complete) event wait, not a stall of
+    the compute stream."""
 
     def __init__(self, predict: Predict, group=None, depth: int = 2):
         self.predict, self.group, self.depth = predict, group, depth
@@ -72,6 +79,8 @@ class ShardedPredictor:
         self.rank = dist.get_rank(group)
         self._slots: List[Optional[dict]] = [None] * depth
         self._count = 0
+        self._side = None  # CUDA side stream of the flag copies
+        self.gather_ms: List[float] = []  # per retired ticket (GPU only): own shard packed -> all ranks' results here (rank skew + transfer)
 
     def _buffers(self, slot: int, max_b: int, tail: Tuple[int, ...], like: torch.Tensor) -> dict:
         s = self._slots[slot]
@@ -80,8 +89,12 @@ class ShardedPredictor:
             s = dict(
                 pad=torch.zeros(shape, dtype=torch.float32, device=like.device),
                 out=torch.empty((self.world * (max_b + 1),) + tail, dtype=torch.float32, device=like.device),
-                work=None, n=0, max_b=max_b, error=None, ticket=-1,
+                work=None, n=0, max_b=max_b, error=None, ticket=-1, flags_host=None, flags_event=None,
             )
+            if like.is_cuda:
+                s["flags_host"] = torch.zeros(self.world, dtype=torch.float32).pin_memory()
+                s["flags_event"] = torch.cuda.Event(enable_timing=True)
+                s["compute_done"] = torch.cuda.Event(enable_timing=True)
             self._slots[slot] = s
         return s
 
@@ -91,8 +104,10 @@ class ShardedPredictor:
         n = int(source.shape[0])
         ticket = self._count
         slot = ticket % self.depth
-        if self._slots[slot] is not None and (self._slots[slot]["work"] is not None or self._slots[slot]["error"] is not None):
-            self._finish(self._slots[slot], False)  # the buffers of `depth` submits ago are free again (a local failure of that submit raises here)
+        if self._slots[slot] is not None and (self._slots[slot]["work"] is not None or not self._slots[slot].get("checked", True)):
+            # the buffers of `depth` submits ago are free again.  A failure of that submit on ANY rank raises here, on
+            # every rank, before anybody joins the new collective
+            self._finish(self._slots[slot], True)
         lo, hi = shard_bounds(n, self.rank, self.world)
         max_b = -(-n // self.world)
         def default_hw():
@@ -119,30 +134,46 @@ class ShardedPredictor:
         if error is not None:
             s["pad"][max_b].fill_(POISON)
         s["n"], s["error"], s["ticket"], s["checked"] = n, error, ticket, False
+        if s["flags_event"] is not None:
+            s["compute_done"].record()  # this rank's shard is packed; what follows until flags_event is the gather (skew + xGMI)
         s["work"] = dist.all_gather_into_tensor(s["out"], s["pad"], group=self.group, async_op=True)
+        if s["flags_event"] is not None:  # flag rows -> pinned host memory, on a side stream, right behind the gather
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=s["out"].device)
+            with torch.cuda.stream(self._side):
+                s["work"].wait()  # stream-level: only the side stream waits for the gather here
+                flags = s["out"].view(self.world, max_b + 1, -1)[:, max_b, 0]
+                s["flags_host"].copy_(flags, non_blocking=True)
+                s["flags_event"].record(self._side)
         self._count += 1
         return ticket
 
     def _finish(self, s: dict, check: bool) -> None:
-        """Complete the slot's gather; with ``check`` read every rank's status row (one tiny device->host copy) and raise
-        ``ShardFailed`` on all ranks if any of them failed."""
+        """Complete the slot's gather; with ``check`` read every rank's status row and raise ``ShardFailed`` -- on all
+        ranks alike, the rows being the gathered ones -- if any of them failed (the local exception is chained on its
+        own rank).  ``check=False`` only waits (stream-level on nccl) and leaves the slot unchecked: the next path that
+        retires it (slot reuse in ``submit``, ``result``, ``drain``) still raises."""
         if s["work"] is not None:
             s["work"].wait()
             s["work"] = None
-        if s["error"] is not None:  # the local failure is known without looking at the buffer
-            err, s["error"] = s["error"], None
-            raise ShardFailed([self.rank], s["ticket"]) from err
         if check and not s.get("checked", False):
-            stride = s["max_b"] + 1
-            flags = s["out"].view(self.world, stride, -1)[:, s["max_b"], 0]
-            bad = [r for r, v in enumerate(flags.tolist()) if v >= 0.5 * POISON]  # (fp32(1e30) != the Python double 1e30)
+            if s["flags_event"] is not None:
+                s["flags_event"].synchronize()
+                flags = s["flags_host"].tolist()
+                self.gather_ms.append(s["compute_done"].elapsed_time(s["flags_event"]))
+            else:
+                stride = s["max_b"] + 1
+                flags = s["out"].view(self.world, stride, -1)[:, s["max_b"], 0].tolist()
+            bad = [r for r, v in enumerate(flags) if v >= 0.5 * POISON]  # (fp32(1e30) != the Python double 1e30)
             s["checked"] = True
+            err, s["error"] = s["error"], None
             if bad:
-                raise ShardFailed(bad, s["ticket"])
+                raise ShardFailed(bad, s["ticket"]) from err
 
-    def wait(self, ticket: int, check: bool = False) -> None:
-        """Wait for the gather of ``ticket`` without assembling the result (stream-level on nccl).  A failure of THIS rank's
-        ``predict`` raises here; ``check=True`` also inspects the other ranks' status rows (a device->host sync)."""
+    def wait(self, ticket: int, check: bool = True) -> None:
+        """Wait for the gather of ``ticket`` without assembling the result.  ``check=True`` (default) reads the gathered
+        status rows and raises ``ShardFailed`` on EVERY rank if any rank's ``predict`` failed; ``check=False`` is a pure
+        stream-level wait (the failure then surfaces, still on every rank, when the slot is next retired)."""
         assert self._count - self.depth <= ticket < self._count, "ticket is no longer (or not yet) in the ring"
         self._finish(self._slots[ticket % self.depth], check)
 
@@ -157,7 +188,7 @@ class ShardedPredictor:
         """Complete every gather in flight; raises ``ShardFailed`` if any rank failed on any of them."""
         failed = None
         for s in self._slots:
-            if s is not None and (s["work"] is not None or s["error"] is not None):
+            if s is not None and (s["work"] is not None or not s.get("checked", True)):
                 try:
                     self._finish(s, True)
                 except ShardFailed as exc:
