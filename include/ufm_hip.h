@@ -33,7 +33,7 @@ extern "C" {
 #define UFM_ERR_ARG (-1)    /* shape / alignment contract violated (nothing was launched) */
 #define UFM_ERR_LAUNCH (-2) /* hipLaunch reported an error */
 
-#define UFM_ABI_VERSION 1
+#define UFM_ABI_VERSION 2 /* 2: relu_in of the conv entry points became a flag word (bit 1 = replicate padding) */
 
 int ufm_abi_version(void);
 const char* ufm_last_error(void);

@@ -115,6 +115,12 @@ class RegressionAdaptorOutput:
 
 
 @dataclass
+class RegressionWithConfidenceAdaptorOutput:
+    value: torch.Tensor
+    confidence: torch.Tensor
+
+
+@dataclass
 class MaskAdaptorOutput:
     logits: torch.Tensor
     mask: torch.Tensor
@@ -924,8 +930,9 @@ class FlowWithConfidenceAdaptor(nn.Module):
         self.flow = FlowAdaptor(name, **{k: v for k, v in kw.items() if k.startswith("flow_")})
         self.conf = ConfidenceAdaptor(name, **{k: v for k, v in kw.items() if not k.startswith("flow_")})
 
-    def forward(self, x: torch.Tensor):
-        return self.flow(x[:, :2]), self.conf(x[:, 2:3])
+    def forward(self, x: torch.Tensor) -> RegressionWithConfidenceAdaptorOutput:
+        # the reference reads only ``.value`` of its "flow" entry (ufm.py:420, 645, 924); the confidence channel rides along
+        return RegressionWithConfidenceAdaptorOutput(value=self.flow(x[:, :2]).value, confidence=self.conf(x[:, 2:3]).value)
 
 
 class AdaptorMap(nn.Module):

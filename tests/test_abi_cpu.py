@@ -57,7 +57,9 @@ def test_header_arg_counts_match_ctypes(lib):
 
 
 def test_version_arch_and_argument_validation(lib):
-    assert lib.ufm_abi_version() == 1
+    from ufm_amd import hip
+
+    assert lib.ufm_abi_version() == hip.ABI_VERSION == 2  # bumped with every change of an argument's meaning (a stale .so fails to load)
     assert lib.ufm_built_arch() == b"gfx950"
     # contract violations are rejected on the host before any launch (works without a GPU)
     rc = lib.ufm_gemm_bf16(ctypes.c_void_p(16), 96, ctypes.c_void_p(16), 96, 4, 128, 96, None, 0, None, None, 0, 0, ctypes.c_void_p(16), 0, 128, 0, None)

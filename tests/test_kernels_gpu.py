@@ -915,6 +915,33 @@ def test_gemm_bf16x3(hip, M, N, K, act, use_gamma, use_res, split_out):
     assert err <= 4e-5 * max(1.0, ref.abs().max().item()), err
 
 
+def test_split_format_gelu_epilogue_against_fp64_gelu(hip):
+    """The GELU of every split-format epilogue (conv_x3_common.h: gelu_erf_fast -- Abramowitz-Stegun 7.1.26 on v_rcp_f32 /
+    v_exp2_f32) measured directly: a 32 x 32 identity weight and every bf16 value of [-8, 8] as the operand, so the
+    accumulator IS x (hi * 1, lo = 0: exact) and the fp32 output is gelu_erf_fast(x) alone.  This GELU serves the precise-mode
+    fc1 and -- since round 3 -- the classification-head MLP in "fast" and "parity_x3heads" too (the DPT heads have no GELU)."""
+    bits = torch.arange(0, 1 << 16, dtype=torch.int32)
+    vals = (bits << 16).view(torch.float32)
+    vals = vals[torch.isfinite(vals) & (vals.abs() <= 8.0)]
+    n = (vals.numel() // 32) * 32
+    x = vals[:n].reshape(-1, 32).contiguous()
+    M = x.shape[0]
+    A = torch.stack([x.bfloat16(), torch.zeros_like(x).bfloat16()])
+    assert torch.equal(A[0].float(), x)  # every operand is a bf16 value: the hi plane alone carries it
+    W = torch.stack([torch.eye(32).bfloat16(), torch.zeros(32, 32).bfloat16()])
+    out = torch.full((M, 32), 7.0, device=DEV)
+    hip.gemm_x3(A.to(DEV), W.to(DEV), M, 32, 32, out, torch.zeros(256, device=DEV), act=1)
+    ref = F.gelu(x.double())
+    err = (out.cpu().double() - ref).abs()
+    rel = err / ref.abs().clamp_min(1e-300)
+    # Measured on MI355X (tools/lab/gelu_probe.py): max |err| 4.4e-7 (at x = 3.27: the erfc polynomial's 1.5e-7 times x / 2, plus
+    # the approximate v_rcp / v_exp2); relative error <= 6e-7 for x >= -1, 5.6e-5 on [-3, -1] and an ABSOLUTE 2.6e-7 below -3,
+    # where gelu itself is < 4e-3 (the formula bounds the absolute error; it does not keep relative accuracy in the negative tail,
+    # unlike gelu_bf16_x4 of the bf16 GEMM).  Against the 2^-17 = 7.6e-6 relative resolution of the split store: an order below it.
+    assert err.max().item() <= 1e-6, err.max().item()
+    assert rel[x >= -1.0].max().item() <= 2e-6 and rel[(x >= -3.0) & (x < -1.0)].max().item() <= 2e-4
+
+
 def test_gemm_bf16x3_rejects_bad_arguments(hip):
     z = torch.zeros(256, device=DEV)
     a, w = torch.zeros(2, 64, 48, device=DEV, dtype=torch.bfloat16), torch.zeros(2, 64, 48, device=DEV, dtype=torch.bfloat16)

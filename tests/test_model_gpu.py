@@ -730,6 +730,29 @@ def test_covariance_and_keypoint_confidence_outputs_vs_oracle(env, numerics):
     assert (c[:, 0] * i[:, 0] + c[:, 2] * i[:, 2] - 1).abs().max() <= 1e-3 and (c[:, 0] * i[:, 2] + c[:, 2] * i[:, 1]).abs().max() <= 1e-3
 
 
+def _flow_with_confidence_config(mod):
+    """Tiny model whose flow head ends in the reference's third selectable flow adaptor (ufm.py:38)."""
+    cfg = mod.ufm_tiny_config()
+    cfg["feature_head_kwargs"]["dpt_processor"]["output_dim"] = 3
+    cfg["adaptors_kwargs"] = dict(flow={"class": "FlowWithConfidenceAdaptor",
+                                        "kwargs": dict(name="flow", flow_mean=(0.5, -0.25), flow_std=(2.0, 3.0), confidence_type="exp", vmin=1.0, vmax=50.0)})
+    return cfg
+
+
+@pytest.mark.parametrize("numerics", ["parity", "fast"])
+def test_flow_with_confidence_adaptor_vs_oracle(env, numerics):
+    """``FlowWithConfidenceAdaptor`` is in the reference's adaptor table (ufm.py:38) and its forward reads ``["flow"].value``
+    (ufm.py:420, 645): a 3-channel flow head whose first two channels are the flow (mean / std applied) and whose third is a
+    confidence.  Formula = the oracle's restatement of the absent class (parity unpinned)."""
+    oracle, prod = build_pair(env, cfg_fn=_flow_with_confidence_config)
+    prod.set_numerics(numerics)
+    src, tgt = u8((2, 56, 56, 3), 15), u8((2, 56, 56, 3), 16)
+    o = oracle.predict_correspondences_batched(src, tgt)
+    p = prod.predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
+    df, dm, rng = compare(o, p)
+    assert df <= (1.5e-3 if numerics == "parity" else 0.02 * rng) and dm <= (1e-3 if numerics == "parity" else 0.02), (df, dm, rng)
+
+
 @pytest.mark.parametrize("name", ["glue_prepost_cov_down_u8.npz", "glue_prepost_cov_ident_u8.npz"])
 def test_covariance_unmap_against_reference_golden(env, golden_dir, name):
     """Pinned: the reference's own _predict_correspondences_batched (base.py:236-334) around a fake forward that returns a

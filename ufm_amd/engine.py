@@ -296,8 +296,9 @@ class Engine:
         self.head_split = self.numerics in ("fast", "precise", "parity_x3heads")
         moge = not isinstance(m.head1[0], nn.Sequential)  # head_type "moge_conv" (ufm.py:266-267): one feature module, not (DPTFeature, processor)
         self.heads = {"head1": (_MoGeHead if moge else _Head)(m.head1, dev, self.head_split)}
-        if hasattr(m, "uncertainty_head"):
-            self.heads["uncertainty_head"] = _Head(m.uncertainty_head, dev, self.head_split)
+        if hasattr(m, "uncertainty_head"):  # built with its own head type (ufm.py:553-556 passes uncertainty_head_type)
+            moge_u = not isinstance(m.uncertainty_head[0], nn.Sequential)
+            self.heads["uncertainty_head"] = (_MoGeHead if moge_u else _Head)(m.uncertainty_head, dev, self.head_split)
         self.refine = hasattr(m, "classification_head")
         if self.refine:
             ch = m.classification_head
@@ -674,6 +675,11 @@ class Engine:
                 logdet = torch.empty((B, 1, H, W), device=self.dev, dtype=torch.float32)
                 hip.adaptor_covariance2d(raw, B, H * W, cov, inv, logdet)
                 res[a.name] = dict(covariance=cov, inv_covariance=inv, log_det=logdet, kind=a.cls_name)
+            elif a.cls_name == "FlowWithConfidenceAdaptor":  # ufm.py:38; only ``.value`` is read by the reference's forward
+                craw = raw[:, 2:3].contiguous()
+                conf = torch.empty_like(craw)
+                hip.adaptor_confidence(craw, a.confidence_type, a.vmin, a.vmax, conf)
+                res[a.name] = dict(value=raw[:, :2], confidence=conf, logits=None, kind=a.cls_name)
             elif a.cls_name == "ConfidenceAdaptor":  # ufm.py:653-654
                 raw = raw.contiguous()
                 val = torch.empty_like(raw)
@@ -700,7 +706,9 @@ class Engine:
         def gn(t, spec, hh, ww, C, name):
             groups, gw_, gb_, eps = spec
             o = self.hbuf(name, (B, hh, ww, C))
-            ws = self.buf(f"{tag}_gn_ws", (hip.group_norm_ws_floats(B, 8 * gh * 8 * gw, 64),))
+            # sized for THIS call's map and group count (buf() re-allocates when a later call needs more): any number of
+            # upsample stages / groups is covered, the kernel cannot check the workspace itself
+            ws = self.buf(f"{tag}_gn_ws_{hh}x{ww}_{groups}", (hip.group_norm_ws_floats(B, hh * ww, groups),))
             hip.group_norm(t, B, hh * ww, C, groups, gw_, gb_, eps, True, o, ws)
             return o
 

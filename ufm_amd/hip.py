@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libufm_hip.so")
 
 F32, BF16, BF16X2 = 0, 1, 2
+ABI_VERSION = 2  # include/ufm_hip.h UFM_ABI_VERSION: bumped whenever an argument changes meaning, so a stale .so fails to load
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 
 _lib: Optional[C.CDLL] = None
@@ -95,7 +96,7 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)
             fn.argtypes = argtypes
             fn.restype = res
-        if l.ufm_abi_version() != 1:
+        if l.ufm_abi_version() != ABI_VERSION:
             raise RuntimeError("libufm_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -430,6 +430,18 @@ class AdaptorSpec(_Holder):
         elif cls_name == "MaskAdaptor":
             self.required_channels = 1
             self.kinds, self.scale, self.shift = [1], [1.0], [0.0]
+        elif cls_name == "FlowWithConfidenceAdaptor":
+            # selectable in the reference's adaptor table (ufm.py:38); its forward reads only ``["flow"].value`` (ufm.py:420, 645):
+            # two flow channels through the tail's affine map, the third finished by ufm_adaptor_confidence ([U], parity unpinned)
+            self.required_channels = 3
+            self.kinds = [0, 0, 0]
+            self.scale = [float(v) for v in kw.get("flow_std", (1.0, 1.0))] + [1.0]
+            self.shift = [float(v) for v in kw.get("flow_mean", (0.0, 0.0))] + [0.0]
+            ctype = kw.get("confidence_type", "exp")
+            if ctype not in ("exp", "sigmoid", "identity"):
+                raise ValueError(f"FlowWithConfidenceAdaptor: unknown confidence_type {ctype!r} (known: 'exp', 'sigmoid', 'identity')")
+            self.confidence_type = {"exp": 0, "sigmoid": 1, "identity": 2}[ctype]
+            self.vmin, self.vmax = float(kw.get("vmin", 1.0)), float(kw.get("vmax", float("inf")))
         elif cls_name == "Covariance2DAdaptor":
             # raw channels out of the tail kernel (kind 0, a = 1, d = 0); ufm_adaptor_covariance2d finishes them
             self.required_channels = 3
