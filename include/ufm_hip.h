@@ -110,10 +110,21 @@ int ufm_rope2d(void* x, int dtype, int rows, int ld, int col0, int ncols, const 
 /* Two-source attention (cross-attention): softmax(scale * q k^T) v with queries from one buffer and keys / values from
  * another ([U] CrossAttention of the cross-attention info-sharing variant; also self-attention on any column layout).
  *   q: [B*Nq][ldq], k / v: [B*Nk][ldkv], out: [B*Nq][ldo]; head h = columns [64 h, 64 h + 64) of each pointer; Nq != Nk allowed.
- * _bf16: bf16 operands (fast), _f32: exact-fp32 MFMA (parity), _bf16x3: UFM_BF16X2 planes (precise; the lo planes follow at
+ * _bf16: bf16 operands (fast; scale == 0 = q pre-scaled by softmax_scale * log2(e): the persistent LDS-DMA kernel), _f32: exact-fp32 MFMA (parity), _bf16x3: UFM_BF16X2 planes (precise; the lo planes follow at
  * B*Nq*ldq, B*Nk*ldkv and B*Nq*ldo elements). */
 int ufm_cross_attention_bf16(const uint16_t* q, int ldq, const uint16_t* k, const uint16_t* v, int ldkv, uint16_t* out, int ldo,
                              int B, int Nq, int Nk, int H, float scale, void* stream);
+/* The general form of the bf16 kernel: batch item b's queries start at row b * q_batch_rows of q, its keys / values at row
+ * b * kv_batch_rows of k / v, its output at row b * out_batch_rows of out (ufm_cross_attention_bf16 = the densely packed case
+ * q_batch_rows = out_batch_rows = Nq, kv_batch_rows = Nk).  This is how the LAST joint-attention layer runs its view-1 queries
+ * only against both views' keys (the reference decodes view 1 only, /root/reference/uniflowmatch/models/ufm.py:637-641): q = the
+ * pair's first Np rows of the qkv buffer (q_batch_rows = 2 Np), k / v = all 2 Np rows.
+ * scale == 0: q is pre-scaled by softmax_scale * log2(e) (the projection GEMM's epilogue does it) and the call runs on the
+ * persistent LDS-DMA kernel of ufm_attention_bf16 (csrc/attention_bf16_pw.hip); scale > 0: the register-staged kernel applies it
+ * (densely packed batch items only).  ldq / ldkv / ldo % 8 == 0, 16-byte aligned pointers. */
+int ufm_attention_bf16_strided(const uint16_t* q, int ldq, int q_batch_rows, const uint16_t* k, const uint16_t* v, int ldkv,
+                               int kv_batch_rows, uint16_t* out, int ldo, int out_batch_rows, int B, int Nq, int Nk, int H,
+                               float scale, void* stream);
 int ufm_cross_attention_f32(const float* q, int ldq, const float* k, const float* v, int ldkv, float* out, int ldo, int B,
                             int Nq, int Nk, int H, float scale, void* stream);
 int ufm_cross_attention_bf16x3(const uint16_t* q, int ldq, const uint16_t* k, const uint16_t* v, int ldkv, uint16_t* out, int ldo,
@@ -174,6 +185,10 @@ int ufm_add_layernorm(float* x, int ldx, const uint16_t* branch, int ldb, const 
  * (cls_token + pos_embed[0]) of the token buffer: out row = g*(group)+0.  ([U] DINOv2 prepare_tokens) */
 int ufm_fill_rows(float* out, int ldo, int n_groups, int group_stride_rows, const float* src, int D,
                   void* stream);
+
+/* out[r, :] = x[row_index[r], :]: compacts selected fp32 rows of the residual stream.  Used by the LAST joint-attention layer,
+ * which only needs its view-1 rows (the reference decodes view 1 only, /root/reference/uniflowmatch/models/ufm.py:637-641). */
+int ufm_gather_rows_f32(const float* x, int ldx, const int32_t* row_index, int rows, int D, float* out, int ldo, void* stream);
 
 /* out[orow(r), :] = a[r, :] + tab[r % tab_mod, :] with the same orow() as ufm_gemm_bf16: fp32 token
  * assembly (patch tokens + pos-embed, cls slot skipped; view positional encoding) for the

@@ -728,6 +728,64 @@ def test_cross_attention_two_sources(hip, B, Nq, Nk, H, fmt):
     assert err <= tol, err
 
 
+@pytest.mark.parametrize("B,Nq,Nk,H", [(1, 17, 40, 1), (2, 100, 37, 2), (2, 300, 1369, 2), (1, 1369, 130, 3), (3, 64, 64, 1), (2, 257, 513, 2)])
+def test_cross_attention_two_sources_prescaled_on_the_persistent_kernel(hip, B, Nq, Nk, H):
+    """ufm_cross_attention_bf16 with scale == 0 (q pre-scaled by softmax_scale * log2 e, as the Q projection's epilogue leaves it):
+    the persistent LDS-DMA kernel of attention_bf16_pw.hip with separate q and k / v sources, Nq != Nk, ragged last key tile and
+    ragged last query block, q inside a wider buffer."""
+    D = H * 64
+    qbuf = bf16r(rnd(B * Nq, D + 64, seed=Nq, scale=1.5))
+    kv = bf16r(rnd(B * Nk, 2 * D, seed=Nk + 1, scale=1.5))
+    ref = cross_attn_ref(qbuf[:, :D], kv[:, :D], kv[:, D:], B, Nq, Nk, H, 0.125)
+    pre = qbuf.clone()
+    pre[:, :D] = bf16r(pre[:, :D] * (0.125 * 1.4426950408889634))
+    qd, kvd = pre.to(DEV).bfloat16(), kv.to(DEV).bfloat16()
+    out = torch.zeros(B * Nq, D, device=DEV, dtype=torch.bfloat16)
+    hip.cross_attention(qd[:, :D], D + 64, kvd[:, :D], kvd[:, D:], 2 * D, out, D, B, Nq, Nk, H, 0.0, hip.BF16)
+    err = (out.float().cpu().double() - ref).abs().max().item()
+    assert err <= 3e-2, err  # bf16 P and O + the test's extra rounding of the pre-scaled q
+
+
+@pytest.mark.parametrize("B,Np,H", [(2, 1369, 2), (3, 100, 1), (1, 37, 3)])
+def test_attention_strided_view1_queries_are_bitwise_the_joint_attention_rows(hip, B, Np, H):
+    """The last joint-attention layer decodes view 1 only (/root/reference/uniflowmatch/models/ufm.py:637-641): its view-1 queries
+    (the first Np of a pair's 2 Np rows, q_batch_rows = 2 Np) against ALL 2 Np keys through ufm_attention_bf16_strided must equal
+    the corresponding rows of the full joint self-attention bit for bit (same kernel, same key-tile order per query row --
+    whenever the 256-row query blocks of the two launches align, i.e. always for the leading rows of a batch item)."""
+    N, D = 2 * Np, H * 64
+    qkv = rnd(B * N, 3 * D, seed=Np, scale=1.5)
+    qkv[:, :D] *= 0.125 * 1.4426950408889634  # pre-scaled q: scores of a few units, so no wave takes the (wave-wide) deferred-rescale path
+    qkv = qkv.to(DEV).bfloat16()
+    full = torch.zeros(B * N, D, device=DEV, dtype=torch.bfloat16)
+    hip.attention(qkv, full, B, N, H, 0.0)
+    half = torch.full((B * Np, D), 7.0, device=DEV, dtype=torch.bfloat16)
+    hip.attention_strided(qkv[:, :D], 3 * D, N, qkv[:, D : 2 * D], qkv[:, 2 * D :], 3 * D, N, half, D, Np, B, Np, N, H)
+    want = full.view(B, 2, Np, D)[:, 0].reshape(B * Np, D)
+    assert torch.equal(half, want)
+    # and into a strided output (rows of a wider buffer, batch items 2 Np rows apart)
+    wide = torch.zeros(B * N, D + 64, device=DEV, dtype=torch.bfloat16)
+    hip.attention_strided(qkv[:, :D], 3 * D, N, qkv[:, D : 2 * D], qkv[:, 2 * D :], 3 * D, N, wide, D + 64, N, B, Np, N, H)
+    assert torch.equal(wide.view(B, 2, Np, D + 64)[:, 0, :, :D].reshape(B * Np, D), want)
+    assert bool((wide.view(B, 2, Np, D + 64)[:, 1] == 0).all()) and bool((wide[:, D:] == 0).all())  # nothing else was written
+
+
+def test_gather_rows_f32(hip):
+    x = rnd(50, 72, seed=3).to(DEV)
+    idx = torch.tensor([49, 0, 7, 7, 13, 48], dtype=torch.int32, device=DEV)
+    out = torch.full((6, 80), 5.0, device=DEV)
+    hip.gather_rows(x[:, :64], 72, idx, 6, 64, out, 80)
+    assert torch.equal(out[:, :64], x[idx.long(), :64]) and bool((out[:, 64:] == 5.0).all())
+
+
+def test_attention_strided_rejects_bad_arguments(hip):
+    q = torch.zeros(128, 192, device=DEV, dtype=torch.bfloat16)
+    o = torch.zeros(64, 64, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="batch strides"):
+        hip.attention_strided(q[:, :64], 192, 32, q[:, 64:128], q[:, 128:], 192, 128, o, 64, 64, 1, 64, 128, 1)
+    with pytest.raises(RuntimeError, match="densely packed"):
+        hip.attention_strided(q[:, :64], 192, 128, q[:, 64:128], q[:, 128:], 192, 128, o, 64, 64, 1, 64, 128, 1, scale=0.125)
+
+
 def rope_ref(x, gh, gw, H, freq=100.0):
     """The oracle's CroCo RoPE2D on a (rows = B*gh*gw, H*64) projection output."""
     from oracle.uniception_ref import RoPE2D, grid_positions

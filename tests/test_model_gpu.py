@@ -545,6 +545,33 @@ def test_full_size_batch_shards_are_bitwise_equal_across_kernel_dispatch(env):
     assert torch.equal(again.flow.flow_output, wf) and torch.equal(again.covisibility.mask, wm)
 
 
+def test_last_joint_attention_layer_on_view1_rows_is_bitwise_the_full_layer(env):
+    """Engine.last_layer_view1 (default on, "fast"): the LAST joint-attention block computes only its view-1 rows -- queries / proj /
+    MLP on half the rows through ufm_attention_bf16_strided, keys and values of both views (the reference decodes view 1 only,
+    /root/reference/uniflowmatch/models/ufm.py:637-641).  Exact: flow and covisibility equal the full block's bit for bit, at the tiny
+    size and at UFM-Base 518^2 (3 pairs: one micro-batch of 1 + one of 2 through the joint heads)."""
+    ufm_amd, _ = env
+    from ufm_amd.modules import init_weights_
+
+    _, tiny = build_pair(env)
+    tiny.set_numerics("fast")
+    base = ufm_amd.UniFlowMatchConfidence(**ufm_amd.ufm_base_config()).eval()
+    init_weights_(base, seed=0)
+    base = base.to(DEV).set_numerics("fast")
+    for model, shape in ((tiny, (3, 56, 56, 3)), (base, (3, 518, 518, 3))):
+        src, tgt = u8(shape, 31).to(DEV), u8(shape, 32).to(DEV)
+        eng = model.engine()
+        assert eng.last_layer_view1
+        a = model.predict_correspondences_batched(src, tgt)
+        af, am = a.flow.flow_output.clone(), a.covisibility.mask.clone()
+        eng.last_layer_view1 = False
+        try:
+            b = model.predict_correspondences_batched(src, tgt)
+        finally:
+            eng.last_layer_view1 = True
+        assert torch.equal(af, b.flow.flow_output) and torch.equal(am, b.covisibility.mask)
+
+
 def test_two_stream_micro_batches_are_repeatable_at_benchmark_batch(env):
     """bench.py's workload itself (UFM-Base, 8 pairs at 518^2 = two concurrent micro-batches of 4): two identical calls
     agree bit for bit and pairs 0 / 4 / 7 equal their one-pair runs.  (A workgroup's first attention unit used to be

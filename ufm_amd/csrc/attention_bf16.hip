@@ -219,6 +219,8 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_kernel(const uint16_t* __res
 }  // namespace
 
 int ufm_launch_attn_pw(const uint16_t* qkv, uint16_t* out, int B, int N, int H, int variant, hipStream_t stream);  // attention_bf16_pw.hip
+int ufm_launch_attn_pw2(const uint16_t* q, int ldq, int q_bs, const uint16_t* k, const uint16_t* v, int ldkv, int kv_bs, uint16_t* out, int ldo, int o_bs,
+                        int B, int Nq, int Nk, int H, int variant, hipStream_t stream);  // attention_bf16_pw.hip
 
 static int g_attn_debug = 0;
 extern "C" int ufm_debug_set_attn_variant(int v) {  // 0 = 4 waves per workgroup (default), 1 = 2 waves per workgroup
@@ -246,12 +248,28 @@ extern "C" int ufm_attention_bf16(const uint16_t* qkv, uint16_t* out, int B, int
 
 extern "C" int ufm_cross_attention_bf16(const uint16_t* q, int ldq, const uint16_t* k, const uint16_t* v, int ldkv, uint16_t* out, int ldo,
                                         int B, int Nq, int Nk, int H, float scale, void* stream) {
-    UFM_REQUIRE(q && k && v && out, "ufm_cross_attention_bf16: null pointer");
-    UFM_REQUIRE(B > 0 && Nq > 0 && Nk > 0 && H > 0 && scale > 0.0f && (int64_t)((Nq + QB - 1) / QB) * H * B < (1ll << 31), "ufm_cross_attention_bf16: bad shape B=%d Nq=%d Nk=%d H=%d", B, Nq, Nk, H);
-    UFM_REQUIRE(ldq >= H * 64 && ldkv >= H * 64 && ldo >= H * 64 && ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 4 == 0, "ufm_cross_attention_bf16: bad leading dimensions %d/%d/%d", ldq, ldkv, ldo);
-    UFM_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 && ((uintptr_t)out % 8) == 0, "ufm_cross_attention_bf16: misaligned pointer");
-    dim3 grid(((Nq + QB - 1) / QB) * H * B), block(256);
-    hipLaunchKernelGGL(attn_bf16_kernel, grid, block, 0, (hipStream_t)stream, q, ldq, k, v, ldkv, out, ldo, Nq, Nk, H, scale * 1.44269504088896340736f);
-    UFM_CHECK_LAUNCH("ufm_cross_attention_bf16");
+    return ufm_attention_bf16_strided(q, ldq, Nq, k, v, ldkv, Nk, out, ldo, Nq, B, Nq, Nk, H, scale, stream);
+}
+
+// The general two-source form: batch item b's queries start at row b * q_batch_rows of `q`, its keys / values at row
+// b * kv_batch_rows of `k` / `v`, its output at row b * out_batch_rows of `out` (rows of ldq / ldkv / ldo elements).
+// scale == 0: Q is pre-scaled by softmax_scale * log2(e) (the projection's epilogue) -> the persistent LDS-DMA kernel of
+// attention_bf16_pw.hip; scale > 0: the register-staged kernel above applies it.
+extern "C" int ufm_attention_bf16_strided(const uint16_t* q, int ldq, int q_batch_rows, const uint16_t* k, const uint16_t* v, int ldkv, int kv_batch_rows,
+                                          uint16_t* out, int ldo, int out_batch_rows, int B, int Nq, int Nk, int H, float scale, void* stream) {
+    UFM_REQUIRE(q && k && v && out, "ufm_attention_bf16_strided: null pointer");
+    UFM_REQUIRE(B > 0 && Nq > 0 && Nk > 0 && H > 0 && scale >= 0.0f && (int64_t)((Nq + QB - 1) / QB) * H * B < (1ll << 31), "ufm_attention_bf16_strided: bad shape B=%d Nq=%d Nk=%d H=%d", B, Nq, Nk, H);
+    UFM_REQUIRE(ldq >= H * 64 && ldkv >= H * 64 && ldo >= H * 64 && ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 8 == 0, "ufm_attention_bf16_strided: bad leading dimensions %d/%d/%d", ldq, ldkv, ldo);
+    UFM_REQUIRE(q_batch_rows >= Nq && kv_batch_rows >= Nk && out_batch_rows >= Nq, "ufm_attention_bf16_strided: batch strides %d/%d/%d rows are shorter than Nq=%d / Nk=%d", q_batch_rows, kv_batch_rows, out_batch_rows, Nq, Nk);
+    UFM_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 && ((uintptr_t)out % 16) == 0, "ufm_attention_bf16_strided: misaligned pointer");
+    UFM_REQUIRE((int64_t)kv_batch_rows * ldkv * 2 < (1ll << 31), "ufm_attention_bf16_strided: one batch item's K/V rows exceed the 32-bit DMA offset");
+    if (scale == 0.0f) {
+        ufm_launch_attn_pw2(q, ldq, q_batch_rows, k, v, ldkv, kv_batch_rows, out, ldo, out_batch_rows, B, Nq, Nk, H, g_attn_debug, (hipStream_t)stream);
+    } else {
+        UFM_REQUIRE(q_batch_rows == Nq && kv_batch_rows == Nk && out_batch_rows == Nq, "ufm_attention_bf16_strided: the scale > 0 kernel takes densely packed batch items only");
+        dim3 grid(((Nq + QB - 1) / QB) * H * B), block(256);
+        hipLaunchKernelGGL(attn_bf16_kernel, grid, block, 0, (hipStream_t)stream, q, ldq, k, v, ldkv, out, ldo, Nq, Nk, H, scale * 1.44269504088896340736f);
+    }
+    UFM_CHECK_LAUNCH("ufm_attention_bf16_strided");
     return UFM_OK;
 }

@@ -136,9 +136,19 @@ __device__ __forceinline__ unsigned long long stamp() {  // cdna_hip_programming
     return t;
 }
 
+// q / k / v: first element of head 0 of batch item 0; ld*: row strides (elements); *_bs: rows between consecutive batch items
+struct PwArgs {
+    const uint16_t *q, *k, *v;
+    uint16_t* out;
+    int ldq, ldkv, ldo, q_bs, kv_bs, o_bs, Nq, Nk, H, nqb, nunits;
+};
+
 template <int NW, bool DIAG>
-__global__ __launch_bounds__(NW * 64, 1) void attn_pw_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int N, int H, int nqb,
-                                                             int nunits, unsigned long long* __restrict__ diag) {
+__global__ __launch_bounds__(NW * 64, 1) void attn_pw_kernel(PwArgs a_, unsigned long long* __restrict__ diag) {
+    // two sources (self-attention: q / k / v are column blocks of one qkv buffer): N = keys per batch item, Nq = query rows
+    const uint16_t* __restrict__ qsrc = a_.q;
+    uint16_t* __restrict__ out = a_.out;
+    const int N = a_.Nk, Nq = a_.Nq, H = a_.H, nqb = a_.nqb, nunits = a_.nunits;
     unsigned long long seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0, t_begin = 0, rt_begin = 0;  // 0-4 key-tile slots, 5-10 unit seams
     if (DIAG) {
         t_begin = stamp();
@@ -158,8 +168,8 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_pw_kernel(const uint16_t* __r
     // Persistent: the workgroup walks units (image, head, 64*NW-row query block) u, u + gridDim.x, ...; the units of one
     // (image, head) are consecutive logical ids and, through xcd_remap, concurrent on one XCD (shared K/V stream in its L2).
     int unit = xcd_remap(blockIdx.x, gridDim.x);
-    const int ld = 3 * H * 64;
-    const unsigned ldb = 2u * ld;
+    const int ld = a_.ldq;               // query row stride (elements)
+    const unsigned ldb = 2u * a_.ldkv;   // key / value row stride (bytes)
     const int ql = lane & 31, hh = lane >> 5;
     const int nt = (N + KB - 1) / KB;
     const uint16_t* base;
@@ -168,11 +178,11 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_pw_kernel(const uint16_t* __r
     int q0;
     auto set_unit = [&](int u) __attribute__((always_inline)) {
         const int qblk = u % nqb, head = (u / nqb) % H, b = u / (nqb * H);
-        base = qkv + (size_t)b * N * ld + head * 64;
-        kp = (const char*)(base + H * 64);
-        vp = (const char*)(base + 2 * H * 64);
+        base = qsrc + (size_t)b * a_.q_bs * ld + head * 64;
+        kp = (const char*)(a_.k + (size_t)b * a_.kv_bs * a_.ldkv + head * 64);
+        vp = (const char*)(a_.v + (size_t)b * a_.kv_bs * a_.ldkv + head * 64);
         q0 = qblk * QB + wave * 64;
-        og = out + ((size_t)b * N + q0) * (H * 64) + head * 64;
+        og = out + ((size_t)b * a_.o_bs + q0) * a_.ldo + head * 64;
     };
     set_unit(unit);
 
@@ -181,7 +191,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_pw_kernel(const uint16_t* __r
     auto load_q = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            const uint16_t* qr = base + (size_t)min(q0 + 32 * a + ql, N - 1) * ld + 8 * hh;
+            const uint16_t* qr = base + (size_t)min(q0 + 32 * a + ql, Nq - 1) * ld + 8 * hh;
 #pragma unroll
             for (int s = 0; s < 4; ++s) qf[a][s] = *(const bf16x8*)(qr + 16 * s);
         }
@@ -553,12 +563,12 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_pw_kernel(const uint16_t* __r
         }
         UFM_STAMP(9)
         // Exactly 8 store instructions per wave when all its 64 rows exist (the count the next unit's vmcnt(8) relies on)
-        stores_in_flight = q0_cur + 64 <= N;
+        stores_in_flight = q0_cur + 64 <= Nq;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = 8 * i + prow;
             const u32x4 v = *(const u32x4*)(ob + row * OSTRIDE + 16 * pslot);
-            if (stores_in_flight || q0_cur + row < N) *(u32x4*)(og_cur + (size_t)row * (H * 64) + 8 * pslot) = v;
+            if (stores_in_flight || q0_cur + row < Nq) *(u32x4*)(og_cur + (size_t)row * a_.ldo + 8 * pslot) = v;
         }
         UFM_STAMP(10)
         if (!has_next) break;
@@ -591,12 +601,31 @@ static int attn_pw_grid(int nunits, int nw) {  // persistent: one workgroup of 4
     return nunits < slots ? nunits : slots;
 }
 
+static PwArgs pw_self_args(const uint16_t* qkv, uint16_t* out, int B, int N, int H, int nw) {
+    const int qb = nw * 64, nqb = (N + qb - 1) / qb;
+    return PwArgs{qkv, qkv + H * 64, qkv + 2 * H * 64, out, 3 * H * 64, 3 * H * 64, H * 64, N, N, N, N, N, H, nqb, nqb * H * B};
+}
+
 int ufm_launch_attn_pw(const uint16_t* qkv, uint16_t* out, int B, int N, int H, int variant, hipStream_t stream) {
     const int nw = (variant & 1) ? 2 : 4;
-    const int qb = nw * 64, nqb = (N + qb - 1) / qb, nunits = nqb * H * B;
-    dim3 grid(attn_pw_grid(nunits, nw)), block(nw * 64);
-    if (nw == 4) hipLaunchKernelGGL((attn_pw_kernel<4, false>), grid, block, 0, stream, qkv, out, N, H, nqb, nunits, nullptr);
-    else hipLaunchKernelGGL((attn_pw_kernel<2, false>), grid, block, 0, stream, qkv, out, N, H, nqb, nunits, nullptr);
+    const PwArgs a = pw_self_args(qkv, out, B, N, H, nw);
+    dim3 grid(attn_pw_grid(a.nunits, nw)), block(nw * 64);
+    if (nw == 4) hipLaunchKernelGGL((attn_pw_kernel<4, false>), grid, block, 0, stream, a, nullptr);
+    else hipLaunchKernelGGL((attn_pw_kernel<2, false>), grid, block, 0, stream, a, nullptr);
+    return 0;
+}
+
+// Two-source form (cross-attention of the "cross_attention" info-sharing variant, ufm.py:193; the last joint-attention layer's
+// view-1 queries against both views' keys): the same kernel, queries / keys+values / output with their own base pointers,
+// row strides and per-batch-item row counts.  Q must be pre-scaled by softmax_scale * log2(e) (the projection's epilogue).
+int ufm_launch_attn_pw2(const uint16_t* q, int ldq, int q_bs, const uint16_t* k, const uint16_t* v, int ldkv, int kv_bs, uint16_t* out, int ldo, int o_bs,
+                        int B, int Nq, int Nk, int H, int variant, hipStream_t stream) {
+    const int nw = (variant & 1) ? 2 : 4;
+    const int qb = nw * 64, nqb = (Nq + qb - 1) / qb;
+    const PwArgs a{q, k, v, out, ldq, ldkv, ldo, q_bs, kv_bs, o_bs, Nq, Nk, H, nqb, nqb * H * B};
+    dim3 grid(attn_pw_grid(a.nunits, nw)), block(nw * 64);
+    if (nw == 4) hipLaunchKernelGGL((attn_pw_kernel<4, false>), grid, block, 0, stream, a, nullptr);
+    else hipLaunchKernelGGL((attn_pw_kernel<2, false>), grid, block, 0, stream, a, nullptr);
     return 0;
 }
 
@@ -605,10 +634,10 @@ int ufm_launch_attn_pw(const uint16_t* qkv, uint16_t* out, int B, int N, int H, 
 //       state init, prologue wait + K reads, seam, drain, epilogue compute, store issue, 0}.
 extern "C" int ufm_debug_attention_stamps(const uint16_t* qkv, uint16_t* out, int B, int N, int H, int waves, unsigned long long* diag, void* stream) {
     UFM_REQUIRE(qkv && out && diag && (waves == 2 || waves == 4), "ufm_debug_attention_stamps: bad arguments");
-    const int qb = waves * 64, nqb = (N + qb - 1) / qb, nunits = nqb * H * B;
-    dim3 grid(attn_pw_grid(nunits, waves)), block(waves * 64);
-    if (waves == 4) hipLaunchKernelGGL((attn_pw_kernel<4, true>), grid, block, 0, (hipStream_t)stream, qkv, out, N, H, nqb, nunits, diag);
-    else hipLaunchKernelGGL((attn_pw_kernel<2, true>), grid, block, 0, (hipStream_t)stream, qkv, out, N, H, nqb, nunits, diag);
+    const PwArgs a = pw_self_args(qkv, out, B, N, H, waves);
+    dim3 grid(attn_pw_grid(a.nunits, waves)), block(waves * 64);
+    if (waves == 4) hipLaunchKernelGGL((attn_pw_kernel<4, true>), grid, block, 0, (hipStream_t)stream, a, diag);
+    else hipLaunchKernelGGL((attn_pw_kernel<2, true>), grid, block, 0, (hipStream_t)stream, a, diag);
     UFM_CHECK_LAUNCH("ufm_debug_attention_stamps");
     return UFM_OK;
 }

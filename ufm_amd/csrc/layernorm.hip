@@ -184,6 +184,17 @@ __global__ __launch_bounds__(256) void fill_rows_kernel(float* out, int ldo, int
     }
 }
 
+// out[r, :] = x[row_index[r], :] (fp32 rows, 16 B per lane)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ x, int ldx, const int32_t* __restrict__ row_index, int rows, int D,
+                                                          float* __restrict__ out, int ldo) {
+    const int nvec = D >> 2;
+    const long long total = (long long)rows * nvec;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / nvec), c = (int)(i - (long long)r * nvec);
+        *(f32x4*)(out + (size_t)r * ldo + c * 4) = *(const f32x4*)(x + (size_t)row_index[r] * ldx + c * 4);
+    }
+}
+
 }  // namespace
 
 template <bool ADD>
@@ -265,5 +276,16 @@ extern "C" int ufm_fill_rows(float* out, int ldo, int n_groups, int group_stride
     dim3 grid(min((total + 255) / 256, 2048)), block(256);
     hipLaunchKernelGGL(fill_rows_kernel, grid, block, 0, (hipStream_t)stream, out, ldo, n_groups, group_stride_rows, src, D);
     UFM_CHECK_LAUNCH("ufm_fill_rows");
+    return UFM_OK;
+}
+
+extern "C" int ufm_gather_rows_f32(const float* x, int ldx, const int32_t* row_index, int rows, int D, float* out, int ldo, void* stream) {
+    UFM_REQUIRE(x && row_index && out, "ufm_gather_rows_f32: null pointer");
+    UFM_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldx >= D && ldo >= D, "ufm_gather_rows_f32: bad shape rows=%d D=%d ldx=%d ldo=%d", rows, D, ldx, ldo);
+    UFM_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0, "ufm_gather_rows_f32: misaligned pointer");
+    const long long total = (long long)rows * (D / 4);
+    dim3 grid((unsigned)min((total + 255) / 256, (long long)4096)), block(256);
+    hipLaunchKernelGGL(gather_rows_kernel, grid, block, 0, (hipStream_t)stream, x, ldx, row_index, rows, D, out, ldo);
+    UFM_CHECK_LAUNCH("ufm_gather_rows_f32");
     return UFM_OK;
 }

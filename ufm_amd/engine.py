@@ -110,6 +110,9 @@ class _XBlk(_Blk):
         self.nxw, self.nxb = _f32(blk.norm2.weight, dev), _f32(blk.norm2.bias, dev)   # the cross-attention's query norm
         ca = blk.cross_attn
         self.q = _Lin(ca.projq, dev, wdt, split)
+        # fast mode: the cross-attention's q projection pre-scales by softmax_scale * log2(e) too, so the two-source attention
+        # runs on the persistent LDS-DMA kernel (ufm_cross_attention_bf16 with scale == 0)
+        self.qxscale = torch.full((d,), 0.125 * LOG2E, device=dev, dtype=torch.float32) if (wdt == torch.bfloat16 and not split) else None
         self.kv = _Lin(_cat_linear(ca.projk, ca.projv), dev, wdt, split)
         self.projx = _Lin(ca.proj, dev, wdt, split)
 
@@ -231,6 +234,10 @@ class Engine:
         self._tables: Dict[Any, Any] = {}
         self._packed_key = None
         self._tls = threading.local()  # .ns = workspace namespace of the micro-batch this thread is running
+        # last_layer_view1: the LAST joint-attention block computes its view-1 rows only (queries, proj, MLP on half the rows; keys /
+        # values still from both views) -- the reference decodes view 1 only (ufm.py:637-641) and nothing else reads that block's
+        # view-2 rows (UFM-Refine's classification head does: off there).  Exact: bit-identical to the full block on the kept rows.
+        self.last_layer_view1 = True
         self.micro_batches = 2  # >1: the batch is split into micro-batches that run concurrently on separate HIP streams
         # joint_heads: the micro-batch streams run the TRUNK only (patchify .. info sharing: GEMM / attention launches whose
         # partial rounds and HBM-bound epilogues overlap across streams); their view-1 feature pyramids land in one
@@ -521,6 +528,27 @@ class Engine:
                 self.linear(hid, w.fc2, M, x, gamma=w.ls2, res=x)
             on_block(i, x)
 
+    def _last_block_view1(self, w: _Blk, y, B: int, Np: int, Di: int, heads: int, v1_rows) -> torch.Tensor:
+        """The last joint-attention block on its view-1 rows only ("fast" numerics): LayerNorm + QKV over all 2 Np tokens of a
+        pair (keys / values of both views), then view-1 queries against all keys (ufm_attention_bf16_strided: q_batch_rows = 2 Np,
+        Nq = Np), proj / MLP on the compact (B Np, Di) view-1 residual rows.  Returns that compact fp32 stream; ``y`` keeps the
+        block's INPUT (its view-2 rows are never needed again: ufm.py:637-641 decodes view 1 only)."""
+        M, M1 = B * 2 * Np, B * Np
+        xn, qkv = self.buf("xn", (M, Di), self.adt), self.buf("qkv", (M, 3 * Di), self.adt)
+        hip.layernorm(y, Di, None, M, Di, w.n1w, w.n1b, 1e-6, xn)
+        self.linear(xn, w.qkv, M, qkv, gamma=w.qscale)
+        ao1 = self.buf("ao_v1", (M1, Di), self.adt)
+        hip.attention_strided(qkv[:, :Di], 3 * Di, 2 * Np, qkv[:, Di : 2 * Di], qkv[:, 2 * Di :], 3 * Di, 2 * Np, ao1, Di, Np, B, Np, 2 * Np, heads)
+        y1 = self.buf("info_x_v1", (M1, Di))
+        hip.gather_rows(y, Di, v1_rows, M1, Di, y1)
+        self.linear(ao1, w.proj, M1, y1, gamma=w.ls1, res=y1)
+        xn1 = self.buf("xn_v1", (M1, Di), self.adt)
+        hip.layernorm(y1, Di, None, M1, Di, w.n2w, w.n2b, 1e-6, xn1)
+        hid1 = self.buf("hid_v1", (M1, w.fc1.n), self.adt)
+        self.linear(xn1, w.fc1, M1, hid1, act=hip.ACT_GELU)
+        self.linear(hid1, w.fc2, M1, y1, gamma=w.ls2, res=y1)
+        return y1
+
     def _view_major_tables(self, B: int, Np: int):
         key = ("vm", B, Np)
         if key not in self._tables:
@@ -564,9 +592,10 @@ class Engine:
                 self.linear(ao, w.proj, Mv, x, gamma=w.ls1, res=x)
                 # cross-attention: queries from this view, keys / values from the other view's normed tokens
                 hip.layernorm(x, Di, None, Mv, Di, w.nxw, w.nxb, 1e-6, xn, split=x3)
-                self.linear_rope(xn, w.q, Mv, qb, rope, Di)
+                self.linear_rope(xn, w.q, Mv, qb, rope, Di, gamma=w.qxscale)
                 self.linear_rope(yn[v], w.kv, Mv, kvb, rope, Di)
-                hip.cross_attention(cols(qb, 0, Di), Di, cols(kvb, 0, Di), cols(kvb, Di, 2 * Di), 2 * Di, cols(ao, 0, Di), Di, B, Np, Np, heads, 0.125, fmt)
+                hip.cross_attention(cols(qb, 0, Di), Di, cols(kvb, 0, Di), cols(kvb, Di, 2 * Di), 2 * Di, cols(ao, 0, Di), Di, B, Np, Np, heads,
+                                    0.0 if w.qxscale is not None else 0.125, fmt)
                 self.linear(ao, w.projx, Mv, x, gamma=w.lsx, res=x)
                 # MLP
                 hip.layernorm(x, Di, None, Mv, Di, w.n2w, w.n2b, 1e-6, xn, split=x3)
@@ -999,13 +1028,20 @@ class Engine:
             if i in self.info_indices:
                 inter.append(self.level_ln(yy, Di, info_v1, B * Np, inw, inb, f"lvl_i{len(inter)}"))
 
+        nlast = len(self.info_blocks) - 1 if not self.info_cross else -1
+        half_last = (self.last_layer_view1 and not self.info_cross and not self.refine and self.numerics == "fast" and not self.defer_residual
+                     and nlast >= 1 and nlast not in self.info_indices and self.info_blocks[nlast].qscale is not None)
+        y_last, last_rows = y, info_v1
         if self.info_cross:
             self._cross_blocks(y, B, Np, gh, gw, on_info)
+        elif half_last:
+            self._blocks(self.info_blocks[:nlast], y, B, 2 * Np, Di, self.info_heads, on_info, needs_x=lambda i: i in self.info_indices or i == nlast - 1)
+            y_last, last_rows = self._last_block_view1(self.info_blocks[nlast], y, B, Np, Di, self.info_heads, info_v1), None
         else:
             self._blocks(self.info_blocks, y, B, 2 * Np, Di, self.info_heads, on_info, needs_x=lambda i: i in self.info_indices)
         if len(inter) != 2:
             raise ValueError("info_sharing.indices must name two blocks (ufm.py:605-606 reads intermediates [0] and [1])")
-        lvl3 = self.level_ln(y, Di, info_v1, B * Np, inw, inb, "lvl3")
+        lvl3 = self.level_ln(y_last, Di, last_rows, B * Np, inw, inb, "lvl3")
         levels = [lvl0, inter[0], inter[1], lvl3]  # ufm.py:603-608 (view-1 pyramid only; view 2's is never decoded)
         dims = [D, Di, Di, Di]
         if levels_only:  # joint_heads: the caller runs the heads on the whole batch

@@ -34,6 +34,7 @@ SIGNATURES = {
     "ufm_gemm_bf16_rope": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp],
     "ufm_rope2d": [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "ufm_cross_attention_bf16": [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp],
+    "ufm_attention_bf16_strided": [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "ufm_cross_attention_f32": [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp],
     "ufm_cross_attention_bf16x3": [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp],
     "ufm_debug_set_gemm_variant": [_i],
@@ -47,6 +48,7 @@ SIGNATURES = {
     "ufm_layernorm": [_vp, _i, _vp, _i, _i, _vp, _vp, _f, _vp, _i, _i, _vp],
     "ufm_layernorm_slice": [_vp, _i, _vp, _i, _i, _vp, _vp, _f, _vp, _i, _i, _i64, _vp],
     "ufm_add_layernorm": [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _f, _vp, _i, _i, _vp],
+    "ufm_gather_rows_f32": [_vp, _i, _vp, _i, _i, _vp, _i, _vp],
     "ufm_fill_rows": [_vp, _i, _i, _i, _vp, _i, _vp],
     "ufm_add_rows": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp],
     "ufm_attention_bf16": [_vp, _vp, _i, _i, _i, _f, _vp],
@@ -216,6 +218,12 @@ def layernorm(x, ldx, row_index, rows_out, D, weight, bias, eps, out, ldo=None, 
     _check(lib().ufm_layernorm(_p(x), ldx, _p(row_index), rows_out, D, _p(weight), _p(bias), eps, _p(out), BF16X2 if split else _dt(out), ldo or D, _stream()), "ufm_layernorm")
 
 
+def gather_rows(x, ldx, row_index, rows, D, out, ldo=None):
+    """out[r] = x[row_index[r]] (fp32 rows)."""
+    _t("ufm_gather_rows_f32", rows * D * 8.0)
+    _check(lib().ufm_gather_rows_f32(_p(x), ldx, _p(row_index), rows, D, _p(out), ldo or D, _stream()), "ufm_gather_rows_f32")
+
+
 def add_layernorm(x, ldx, branch, gamma, rows, D, weight, bias, eps, out, ldo=None, split=False):
     """x[r] += gamma * branch[r] (x updated in place), then out = LayerNorm(x).  branch: bf16 (rows, D)."""
     _t("ufm_add_layernorm", rows * D * (4.0 + 2.0 + 4.0 + (4 if split else out.element_size())))
@@ -272,6 +280,14 @@ def cross_attention(q, ldq, k, v, ldkv, out, ldo, B, Nq, Nk, H, scale, fmt):
         TIMER._open = None
     if rc != 0:
         raise RuntimeError(f"{name} failed (rc={rc}): {lib().ufm_last_error().decode()}")
+
+
+def attention_strided(q, ldq, q_batch_rows, k, v, ldkv, kv_batch_rows, out, ldo, out_batch_rows, B, Nq, Nk, H, scale=0.0):
+    """bf16 two-source attention with explicit per-batch-item row strides (ufm_attention_bf16_strided); scale = 0: q pre-scaled,
+    the persistent LDS-DMA kernel."""
+    _t("ufm_attention_bf16", 4.0 * B * H * Nq * Nk * 64)
+    _check(lib().ufm_attention_bf16_strided(_p(q), ldq, q_batch_rows, _p(k), _p(v), ldkv, kv_batch_rows, _p(out), ldo, out_batch_rows, B, Nq, Nk, H, scale, _stream()),
+           "ufm_attention_bf16_strided")
 
 
 def conv2d(x, B, H, W, Cin, weight, Cout, KH, KW, stride, pad, out, zero_page, *, relu_in=False, bias=None, act=ACT_NONE, gamma=None, res1=None, res2=None, shuffle=0, replicate=False):
