@@ -198,6 +198,11 @@ def main():
     ap.add_argument("--gemm-variant", type=int, default=0, help="tuning hook: ufm_debug_set_gemm_variant (0 = auto)")
     ap.add_argument("--attn-variant", type=int, default=0, help="tuning hook: ufm_debug_set_attn_variant (0 = default)")
     ap.add_argument("--concurrent-heads", type=int, default=-1, help="DPT heads on separate streams: -1 = engine default (automatic: only in single-stream forwards), 0 / 1 = force")
+    ap.add_argument("--info-sharing", default="global_attention", choices=["global_attention", "cross_attention"],
+                    help="side measurement (SURVEY 8(f)4): the cross-attention info-sharing variant (ufm.py:193) at UFM-Base dimensions")
+    ap.add_argument("--rope", type=float, default=0.0, help="with --info-sharing cross_attention: RoPE-2D base frequency (0 = none)")
+    ap.add_argument("--head", default="dpt", choices=["dpt", "moge_conv"], help="side measurement (SURVEY 8(f)4): the MoGe convolutional flow head (ufm.py:266-267)")
+    ap.add_argument("--last-layer-view1", type=int, default=1, help="0: the last joint-attention block on all rows (A/B of Engine.last_layer_view1)")
     ap.add_argument("--micro-batches", type=int, default=2, help="concurrent micro-batches (HIP streams) per GPU; 1 = single stream")
     args = ap.parse_args()
 
@@ -235,10 +240,21 @@ def main():
     hip.lib().ufm_debug_set_attn_variant(args.attn_variant)
     res = args.res
     cfg = ufm_amd.ufm_base_config(resolution_wh=(res, res))
+    variant = []
+    if args.info_sharing == "cross_attention":  # same width / depth / heads as the assumed UFM-Base joint-attention trunk
+        cfg["info_sharing_str"] = "cross_attention"
+        cfg["info_sharing_kwargs"] = dict(name="info_sharing", input_embed_dim=1024, num_views=2, depth=12, dim=768, num_heads=12,
+                                          rope_freq=args.rope or None, init_values=None)
+        variant.append("cross_attention info sharing" + (f" + RoPE-2D (freq {args.rope:g})" if args.rope else ""))
+    if args.head == "moge_conv":  # MoGe's default widths on the four UFM-Base pyramid levels
+        cfg["head_type"] = "moge_conv"
+        cfg["feature_head_kwargs"] = dict(input_feature_dims=[1024, 768, 768, 768], dim_out=[2], dim_proj=512, dim_upsample=[256, 128, 128], last_conv_channels=32)
+        variant.append("moge_conv flow head")
     model = ufm_amd.UniFlowMatchConfidence(**cfg).eval()
     init_weights_(model, seed=0)  # deterministic CPU RNG: identical weights on every rank
     model = model.to(dev).set_numerics(args.numerics)
     model.engine().micro_batches = args.micro_batches
+    model.engine().last_layer_view1 = bool(args.last_layer_view1)
     if args.concurrent_heads >= 0:
         model.engine().concurrent_heads = bool(args.concurrent_heads)
 
@@ -327,6 +343,9 @@ def main():
             "micro_batches_per_gpu": args.micro_batches,
         },
     }
+    if variant:  # NOT the headline configuration: a side measurement of a SURVEY 8(f)4 variant
+        line["config"]["variant"] = ", ".join(variant)
+        line["metric"] += " [variant: " + ", ".join(variant) + "]"
 
     # ---- N > 1: the gathered result of ANOTHER rank's shard equals this rank's own recomputation, bit for bit ----
     if use_dist:

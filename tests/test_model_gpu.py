@@ -182,6 +182,15 @@ def test_cross_attention_info_sharing_vs_oracle(env, rope_freq, refine):
     df, dm, mx = compare(o, p)
     print(f"cross_attention (rope={rope_freq}, refine={refine}) fast: flow max-abs {df:.3g} (range {mx:.3g}), mask {dm:.3g}")
     assert df <= 0.02 * mx and dm <= 0.02, (df, dm, mx)
+    # two concurrent micro-batch streams (B >= 4): bitwise the single-stream result (the variant keeps per-micro-batch heads)
+    s4, t4 = u8((4, 56, 56, 3), 23).to(DEV), u8((4, 56, 56, 3), 24).to(DEV)
+    two = prod.predict_correspondences_batched(s4, t4).flow.flow_output.clone()
+    prod.engine().micro_batches = 1
+    try:
+        one = prod.predict_correspondences_batched(s4, t4).flow.flow_output
+    finally:
+        prod.engine().micro_batches = 2
+    assert torch.equal(one, two)
     # view order matters in this variant (each view has its own branch): swapping the inputs is a different computation
     q = prod.set_numerics("parity").predict_correspondences_batched(tgt.to(DEV), src.to(DEV))
     assert (q.flow.flow_output - prod.predict_correspondences_batched(src.to(DEV), tgt.to(DEV)).flow.flow_output).abs().max().item() > 1e-3

@@ -834,9 +834,15 @@ class Engine:
         bounds = [(i * B) // nmb for i in range(nmb + 1)]
         gh, gw = H // self.P, W // self.P
         self._pos_tables(H, W)  # shared read-only tables are built here, before the workers start
-        self._view_pe_table(gh * gw)
+        if self.info_cross:
+            if self.rope_freq:
+                self._rope_tables(gh, gw)
+        else:
+            self._view_pe_table(gh * gw)
         for i in range(nmb):
             self._index_tables(bounds[i + 1] - bounds[i], gh * gw)
+            if self.info_cross:
+                self._view_major_tables(bounds[i + 1] - bounds[i], gh * gw)
         while len(self._streams) < nmb:
             self._streams.append(torch.cuda.Stream(device=self.dev))
         cur = torch.cuda.current_stream(self.dev)
