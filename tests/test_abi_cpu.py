@@ -115,3 +115,19 @@ def test_attention_isa_audit_runs_in_the_build_and_is_not_vacuous(tmp_path):
         bad.write_text(txt.replace(old, new, 1))
         r = subprocess.run([sys.executable, tool, str(bad)], capture_output=True, text=True)
         assert r.returncode != 0 and "ATTN-ISA-AUDIT FAIL" in r.stdout, (old, r.stdout[-500:])
+
+
+def test_host_side_of_the_abi_under_asan_and_ubsan():
+    """SURVEY section 5's sanitizer build: the host code of every entry point (argument validation, error plumbing, the GEMM / conv
+    dispatch cost models, launch bookkeeping) compiled with AddressSanitizer + UBSan (`make -C ufm_amd/csrc asan`: device code
+    un-instrumented, CPU only -- GPU ASan needs xnack+, which the pool refuses) and driven by tools/asan_abi_driver.py under
+    LD_PRELOAD of the sanitizer runtime.  Any report aborts the child."""
+    csrc = os.path.join(REPO, "ufm_amd", "csrc")
+    subprocess.run(["make", "-C", csrc, "asan", "-j8"], check=True, capture_output=True, timeout=900)
+    rt = subprocess.run(["/opt/rocm/bin/hipcc", "-print-file-name=libclang_rt.asan-x86_64.so"], check=True, capture_output=True, text=True).stdout.strip()
+    assert os.path.exists(rt), rt
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "asan_abi_driver.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "asan abi driver ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

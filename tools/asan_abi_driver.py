@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Drives the host side of the C ABI in the AddressSanitizer + UBSan build (ufm_amd/libufm_hip_asan.so, `make -C ufm_amd/csrc asan`):
+every entry point's argument validation with hostile arguments, the error-string plumbing, and -- past validation -- the GEMM /
+conv dispatch cost models and the launch bookkeeping (on a box without a GPU the launch itself fails cleanly with
+UFM_ERR_LAUNCH; device code is never run here).  Run under LD_PRELOAD of the sanitizer runtime (tests/test_abi_cpu.py does);
+any sanitizer report aborts the process with a non-zero exit code."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ufm_amd import hip  # noqa: E402  (signature table only; its own loader is not used)
+
+lib = C.CDLL(os.path.join(ROOT, "ufm_amd", "libufm_hip_asan.so"))
+for name, argtypes in hip.SIGNATURES.items():
+    fn = getattr(lib, name)
+    fn.argtypes, fn.restype = argtypes, C.c_int
+lib.ufm_last_error.restype = C.c_char_p
+lib.ufm_abi_version.restype = C.c_int
+assert lib.ufm_abi_version() == hip.ABI_VERSION
+P = C.c_void_p(4096)  # a non-null, 16-byte aligned fake device pointer: never dereferenced on the host
+calls = 0
+
+
+def expect(rc_ok, rc, what):
+    global calls
+    calls += 1
+    msg = lib.ufm_last_error()
+    assert rc in rc_ok, (what, rc, msg)
+    assert rc == 0 or (msg and len(msg) > 0), what
+
+
+# 1. every entry point with all-zero / null arguments: must be rejected (or be a setter), never crash
+for name, argtypes in hip.SIGNATURES.items():
+    args = []
+    for t in argtypes:
+        if t is C.c_void_p:
+            args.append(None)
+        elif t in (C.c_int, C.c_int64):
+            args.append(0)
+        elif t is C.c_float:
+            args.append(0.0)
+        else:  # pointer to a small host array
+            args.append(None)
+    rc = getattr(lib, name)(*args)
+    expect((0, -1, -2), rc, name)
+# 2. shape contracts of the hot entry points
+expect((-1,), lib.ufm_gemm_bf16(P, 96, P, 96, 4, 128, 96, None, 0, None, None, 0, 0, P, 0, 128, 0, None), "gemm K % 64")
+expect((-1,), lib.ufm_gemm_bf16(P, 64, P, 64, 4, 100, 64, None, 0, None, None, 0, 0, P, 0, 128, 0, None), "gemm N % 128")
+expect((-1,), lib.ufm_gemm_bf16(P, 64, P, 64, 1 << 30, 1 << 20, 64, None, 0, None, None, 0, 0, P, 0, 1 << 20, 0, None), "gemm too large")
+expect((-1,), lib.ufm_attention_bf16(None, None, 1, 1, 1, 0.125, None), "attention null")
+expect((-1,), lib.ufm_attention_bf16_strided(P, 64, 16, P, P, 64, 128, P, 64, 64, 1, 64, 128, 1, 0.0, None), "strided batch rows")
+expect((-1,), lib.ufm_attention_bf16_strided(P, 60, 64, P, P, 64, 128, P, 64, 64, 1, 64, 128, 1, 0.0, None), "strided ldq")
+expect((-1,), lib.ufm_gather_rows_f32(P, 62, P, 4, 64, P, 64, None), "gather ld")
+expect((-1,), lib.ufm_debug_set_gemm_variant(3), "variant")
+expect((-1,), lib.ufm_debug_set_gemm_tile_rows(100), "tile rows")
+# 3. past validation: the dispatch cost models over a sweep of shapes, every variant / tile-height override (a launch without a
+#    GPU returns UFM_ERR_LAUNCH after the host code has run; with a GPU the fake pointers must not be used: skip there)
+try:
+    import torch
+
+    has_gpu = torch.cuda.is_available()
+except Exception:
+    has_gpu = False
+if not has_gpu:
+    for variant in (0, 1, 4, 5):
+        lib.ufm_debug_set_gemm_variant(variant)
+        for rows in (0, 160, 192, 224, 256):
+            lib.ufm_debug_set_gemm_tile_rows(rows)
+            for M in (1, 127, 2738, 10952, 21920, 65536):
+                for N, K in ((128, 64), (768, 768), (1024, 1024), (1024, 4096), (3072, 1024), (4096, 1024), (2304, 768)):
+                    for out_dtype in (0, 1):
+                        rc = lib.ufm_gemm_bf16(P, K, P, K, M, N, K, P, 1 if out_dtype else 0, P if not out_dtype else None, P if not out_dtype else None, N, 0, P, out_dtype, N, 0, None)
+                        expect((0, -2), rc, ("gemm dispatch", variant, rows, M, N, K, out_dtype))
+    lib.ufm_debug_set_gemm_variant(0)
+    lib.ufm_debug_set_gemm_tile_rows(0)
+    for B, H, Cin, Cout, k in ((1, 19, 256, 256, 3), (8, 148, 256, 256, 3), (8, 296, 256, 128, 3), (2, 74, 768, 256, 1), (1, 37, 32, 32, 3)):
+        rc = lib.ufm_conv2d_nhwc_bf16x3(P, B, H, H, Cin, P, Cout, k, k, 1, k // 2, 0, P, 0, None, None, 0, P, None, P, 3, None)
+        expect((0, -2), rc, ("conv dispatch", B, H, Cin, Cout, k))
+    expect((0, -2), lib.ufm_attention_bf16(P, P, 2, 1370, 16, 0.0, None), "attention launch bookkeeping")
+    expect((0, -2), lib.ufm_layernorm(P, 1024, None, 100, 1024, P, P, 1e-6, P, 1, 1024, None), "layernorm")
+print(f"asan abi driver ok: {calls} calls, no sanitizer report")
