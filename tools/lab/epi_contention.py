@@ -33,17 +33,21 @@ def bench(M, N, K, mode, flag_sets, rows=256, reps=7, inner=5):
     return {f: sorted(t)[len(t) // 2] for f, t in times.items()}
 
 
-print("== one round, varying the number of busy CUs: time with epilogue / without (flags 4) ==")
-for N, K, mode in ((1024, 1024, "res"), (3072, 1024, "bf16"), (4096, 1024, "gelu"), (1024, 4096, "res")):
-    ntn = N // 256
-    for tiles in (32, 64, 128, 256):
-        if tiles % ntn: continue
-        M = 256 * (tiles // ntn)
-        r = bench(M, N, K, mode, (0, 4))
-        print(f"N={N} K={K} {mode}: tiles={tiles:4d} M={M:6d}  full {r[0]:7.1f} us  no-epilogue {r[4]:7.1f} us  epilogue {r[0]-r[4]:6.1f} us", flush=True)
+if "--nt-only" not in sys.argv:
+    print("== one round, varying the number of busy CUs: time with epilogue / without (flags 4) ==")
+    for N, K, mode in ((1024, 1024, "res"), (3072, 1024, "bf16"), (4096, 1024, "gelu"), (1024, 4096, "res")):
+        ntn = N // 256
+        for tiles in (32, 64, 128, 256):
+            if tiles % ntn: continue
+            M = 256 * (tiles // ntn)
+            r = bench(M, N, K, mode, (0, 4))
+            print(f"N={N} K={K} {mode}: tiles={tiles:4d} M={M:6d}  full {r[0]:7.1f} us  no-epilogue {r[4]:7.1f} us  epilogue {r[0]-r[4]:6.1f} us", flush=True)
 
-print("== staggered first round at the benchmark shapes (units x ~1 us x (block/8)%4) ==")
-for M, N, K, mode, rows in ((21920, 1024, 1024, "res", 192), (21920, 1024, 4096, "res", 192), (21920, 3072, 1024, "bf16", 256), (21920, 4096, 1024, "gelu", 256),
-                            (10960, 1024, 1024, "res", 192), (10960, 3072, 1024, "bf16", 256)):
-    r = bench(M, N, K, mode, (0, 0x10000, 0x20000, 0x30000, 0x50000), rows=rows)
-    print(f"M={M} N={N} K={K} {mode} rows={rows}: " + "  ".join(f"stagger {f >> 16}: {t:6.1f} us" for f, t in r.items()), flush=True)
+    print("== staggered first round at the benchmark shapes (units x ~1 us x (block/8)%4) ==")
+    for M, N, K, mode, rows in ((21920, 1024, 1024, "res", 192), (21920, 1024, 4096, "res", 192), (21920, 3072, 1024, "bf16", 256), (21920, 4096, 1024, "gelu", 256),
+                                (10960, 1024, 1024, "res", 192), (10960, 3072, 1024, "bf16", 256)):
+        r = bench(M, N, K, mode, (0, 0x10000, 0x20000, 0x30000, 0x50000), rows=rows)
+        print(f"M={M} N={N} K={K} {mode} rows={rows}: " + "  ".join(f"stagger {f >> 16}: {t:6.1f} us" for f, t in r.items()), flush=True)
+
+# (A third arm -- nontemporal residual loads / stores in the read-modify-write epilogue -- was measured in a lab build and reverted:
+#  6-28 % slower on every shape; profiles/r04/gemm_epilogue_contention.log section (c).)
