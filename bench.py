@@ -202,6 +202,7 @@ def main():
                     help="side measurement (SURVEY 8(f)4): the cross-attention info-sharing variant (ufm.py:193) at UFM-Base dimensions")
     ap.add_argument("--rope", type=float, default=0.0, help="with --info-sharing cross_attention: RoPE-2D base frequency (0 = none)")
     ap.add_argument("--head", default="dpt", choices=["dpt", "moge_conv"], help="side measurement (SURVEY 8(f)4): the MoGe convolutional flow head (ufm.py:266-267)")
+    ap.add_argument("--group-heads", type=int, default=0, help="1: the two DPT heads as one grouped launch per layer (Engine.group_heads; measured 1 %% slower than the default two launch sequences on two streams)")
     ap.add_argument("--last-layer-view1", type=int, default=1, help="0: the last joint-attention block on all rows (A/B of Engine.last_layer_view1)")
     ap.add_argument("--micro-batches", type=int, default=2, help="concurrent micro-batches (HIP streams) per GPU; 1 = single stream")
     args = ap.parse_args()
@@ -255,6 +256,7 @@ def main():
     model = model.to(dev).set_numerics(args.numerics)
     model.engine().micro_batches = args.micro_batches
     model.engine().last_layer_view1 = bool(args.last_layer_view1)
+    model.engine().group_heads = bool(args.group_heads)
     if args.concurrent_heads >= 0:
         model.engine().concurrent_heads = bool(args.concurrent_heads)
 
@@ -382,7 +384,7 @@ def main():
                 peak = MFMA_PEAKS[name]
                 entry.update(bound="mfma", algorithmic_gflop=work / 1e9, achieved=work / (d["ms"] * 1e-3) / 1e12, peak=peak, unit="TFLOP/s")
                 entry["frac"] = entry["achieved"] / peak
-                if name in ("ufm_gemm_bf16", "ufm_gemm_bf16x3"):
+                if name in ("ufm_gemm_bf16", "ufm_gemm_bf16x3", "ufm_conv2d_nhwc_bf16x3"):
                     entry["per_shape"] = per_shape_table([r for r in records if r[0] == name], peak)
             elif work:
                 entry.update(bound="hbm", algorithmic_gb=work / 1e9, achieved=work / (d["ms"] * 1e-3) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s")

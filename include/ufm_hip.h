@@ -259,6 +259,17 @@ int ufm_conv2d_nhwc_bf16x3(const uint16_t* in, int B, int H, int W, int Cin, con
                                          the arithmetic bf16 autocast gives the reference's UNet (ufm.py:915-917) */,
                            void* stream);
 
+/* `groups` convolutions of IDENTICAL geometry in one launch: the two DPT heads are the same graph with different weights
+ * (/root/reference/uniflowmatch/models/ufm.py:553-556, 637-642), so each of their layers is one grid of twice the tiles --
+ * fuller rounds on the small maps, no stream ping-pong.  B, H, W: per group.  weight: [2][groups][Cout][KH][KW][Cin]; bias:
+ * [groups][Cout] ([groups][Cout / shuffle^2] in shuffle mode); in: [2][groups * B] images, or [2][B] images read by every group
+ * when in_shared != 0 (the pyramid level both heads start from); res1 / res2 / out / out_relu: [2][groups * B] images, group-major.
+ * Every group's result is bit-identical to its own ufm_conv2d_nhwc_bf16x3 call.  groups == 1 is that call. */
+int ufm_conv2d_nhwc_bf16x3_grouped(const uint16_t* in, int groups, int in_shared, int B, int H, int W, int Cin,
+                                   const uint16_t* weight, int Cout, int KH, int KW, int stride, int pad, int relu_in,
+                                   const float* bias, int act, const uint16_t* res1, const uint16_t* res2, int shuffle,
+                                   uint16_t* out, uint16_t* out_relu, const uint16_t* zero_page, int passes, void* stream);
+
 /* =====================================================================================
  * Numerics mode "precise": the transformer trunk on the split format (fp32-class accuracy at bf16 MFMA rates / 3).
  * Replaces the same nn.Linear / SDPA call sites as ufm_gemm_bf16 / ufm_attention_bf16 ([U] Attention.qkv/proj,
@@ -307,7 +318,9 @@ int ufm_head_tail(const void* x, int in_dtype /* UFM_F32 | UFM_BF16X2 */, int P,
 int ufm_dpt_tail_fused(const uint16_t* in, int B, int h, int w, int Cin, const uint16_t* w2, const float* b2,
                        int Cmid, int H, int W, const float* wt, const float* bt, int Ct,
                        const int32_t* kind_host, const float* a_host, const float* d_host, float* out,
-                       float* out_logits, void* stream);
+                       float* out_logits, int64_t in_plane /* elements between the hi and lo plane of `in`; 0 = B*h*w*Cin (densely packed). Non-zero when `in` is one head's
+                          slice of a stacked multi-head buffer (ufm_conv2d_nhwc_bf16x3_grouped) */,
+                       void* stream);
 
 /* Output adaptors that are not a per-channel affine / sigmoid ([U] uniception prediction_heads.adaptors; the
  * uncertainty head's optional branches, call sites models/ufm.py:648-654).  `raw` = the decoded channels as written by

@@ -1119,6 +1119,54 @@ def test_conv2d_bf16x3_8phase_bit_identical(hip, B, H, W, Cin, Cout, k, stride, 
         assert torch.equal(unsplit(outs[3][1]), torch.relu(unsplit(outs[3][0])))
 
 
+@pytest.mark.parametrize(
+    "B,H,W,Cin,Cout,k,stride,pad,act,nres,shuffle,shared",
+    [
+        (2, 37, 37, 256, 256, 3, 1, 1, 0, 2, 0, False),   # small grid: 64x64 tiles / deep ring
+        (8, 37, 37, 256, 256, 3, 1, 1, 2, 1, 0, False),   # 128-row kernels or the 8-phase kernel on the doubled grid
+        (4, 74, 74, 256, 256, 3, 1, 1, 0, 2, 0, False),   # 8-phase, partial round
+        (5, 148, 148, 64, 256, 3, 1, 1, 0, 0, 0, False),  # 8-phase whole rounds + the hybrid rest launch (ragged last tile per group)
+        (3, 19, 23, 128, 96, 1, 1, 0, 0, 0, 0, True),     # 1x1 projection of a SHARED input (the pyramid level both heads read)
+        (2, 21, 21, 64, 64, 3, 2, 1, 0, 0, 0, False),     # stride 2
+        (2, 9, 11, 64, 256, 1, 1, 0, 0, 0, 2, True),      # ConvTranspose (pixel shuffle), shared input
+        (2, 40, 40, 256, 128, 3, 1, 1, 0, 0, 0, False),   # Cout = 128 (p_conv1's shape)
+    ],
+)
+def test_conv2d_bf16x3_grouped_is_bitwise_the_separate_launches(hip, B, H, W, Cin, Cout, k, stride, pad, act, nres, shuffle, shared):
+    """ufm_conv2d_nhwc_bf16x3_grouped: two convolutions of identical geometry (the two DPT heads' layers) in one grid must give,
+    group by group, exactly the bits of two separate launches -- whatever kernel / tile shape / hybrid split the doubled grid
+    selects -- with per-group weights and bias, shared or per-group inputs, both residuals and the relu second output."""
+    G = 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    Co = Cout // (shuffle * shuffle) if shuffle else Cout
+    xs = [split(nhwc(rnd(B, Cin, H, W, seed=1 + (0 if shared else g)))).to(DEV) for g in range(G)]
+    ws = [split(rnd(Cout, k, k, Cin, seed=20 + g, scale=(Cin * k * k) ** -0.5)).to(DEV) for g in range(G)]
+    bs = [rnd(Co, seed=30 + g, scale=0.1).to(DEV) for g in range(G)]
+    res = [[split(rnd(B, Ho, Wo, Cout, seed=40 + 10 * i + g)).to(DEV) for g in range(G)] for i in range(nres)]
+    oshape = (2, B, Ho * shuffle, Wo * shuffle, Co) if shuffle else (2, B, Ho, Wo, Cout)
+    zero = torch.zeros(256, device=DEV)
+    want, want_r = [], []
+    for g in range(G):
+        out = torch.full(oshape, 7.0, device=DEV, dtype=torch.bfloat16)
+        orl = None if shuffle else torch.full(oshape, 7.0, device=DEV, dtype=torch.bfloat16)
+        hip.conv2d_x3(xs[g], B, H, W, Cin, ws[g], Cout, k, k, stride, pad, out, zero, bias=bs[g], act=act,
+                      res1=res[0][g] if nres > 0 else None, res2=res[1][g] if nres > 1 else None, shuffle=shuffle, out_relu=orl)
+        want.append(out)
+        want_r.append(orl)
+    cat = lambda ts: torch.cat(ts, dim=1).contiguous()  # noqa: E731  (2, G*B, ...): planes outermost, groups stacked on the batch
+    xg = xs[0] if shared else cat(xs)
+    wg = torch.stack(ws, dim=1).contiguous()   # (2, G, Cout, k, k, Cin)
+    bg = torch.stack(bs, dim=0).contiguous()   # (G, Co)
+    gshape = (2, G * B) + tuple(oshape[2:])
+    out = torch.full(gshape, 7.0, device=DEV, dtype=torch.bfloat16)
+    orl = None if shuffle else torch.full(gshape, 7.0, device=DEV, dtype=torch.bfloat16)
+    hip.conv2d_x3(xg, B, H, W, Cin, wg, Cout, k, k, stride, pad, out, zero, bias=bg, act=act,
+                  res1=cat(res[0]) if nres > 0 else None, res2=cat(res[1]) if nres > 1 else None, shuffle=shuffle, out_relu=orl, groups=G, in_shared=shared)
+    assert torch.equal(out.view(torch.int16), cat(want).view(torch.int16))
+    if not shuffle:
+        assert torch.equal(orl.view(torch.int16), cat(want_r).view(torch.int16))
+
+
 @pytest.mark.parametrize("s,Cin,Co", [(4, 32, 32), (2, 64, 48)])
 def test_conv_transpose_bf16x3(hip, s, Cin, Co):
     B, H, W = 2, 5, 7

@@ -581,6 +581,38 @@ def test_last_joint_attention_layer_on_view1_rows_is_bitwise_the_full_layer(env)
         assert torch.equal(af, b.flow.flow_output) and torch.equal(am, b.covisibility.mask)
 
 
+def test_grouped_head_launches_are_bitwise_the_per_head_launches(env):
+    """Engine.group_heads (an option; off by default -- it measured 1 % slower than the two-stream heads): the flow head and the covisibility head -- the same DPT graph with different weights
+    (/root/reference/uniflowmatch/models/ufm.py:553-556, 637-642) -- run every layer up to p_conv1 as ONE grouped launch
+    (ufm_conv2d_nhwc_bf16x3_grouped) on a head-major stacked batch, then their own fused tails.  Bit-identical to the per-head
+    launches: at a small model with the UFM-Base head widths (feature_dim 256 -> the 128 -> 32 tail), odd batch, in "fast" and
+    "parity_x3heads", and at UFM-Base 518^2."""
+    ufm_amd, _ = env
+    from ufm_amd.configs import make_config
+    from ufm_amd.modules import init_weights_
+
+    small_cfg = make_config(enc_dim=128, enc_depth=2, enc_heads=2, info_dim=128, info_depth=4, info_heads=2, layer_dims=(32, 64, 96, 128), feature_dim=256,
+                            resolution_wh=(56, 70), native_img_size=56)
+    cases = [(small_cfg, (3, 70, 56, 3), ("fast", "parity_x3heads")), (ufm_amd.ufm_base_config(), (2, 518, 518, 3), ("fast",))]
+    for cfg, shape, modes in cases:
+        model = ufm_amd.UniFlowMatchConfidence(**cfg).eval()
+        init_weights_(model, seed=0)
+        model = model.to(DEV)
+        src, tgt = u8(shape, 41).to(DEV), u8(shape, 42).to(DEV)
+        for mode in modes:
+            model.set_numerics(mode)
+            eng = model.engine()
+            eng.group_heads = True
+            try:
+                a = model.predict_correspondences_batched(src, tgt)
+            finally:
+                eng.group_heads = False
+            assert eng._head_group is not None and eng._head_group.groups == 2  # the grouped path really ran
+            af, am = a.flow.flow_output.clone(), a.covisibility.mask.clone()
+            b = model.predict_correspondences_batched(src, tgt)
+            assert torch.equal(af, b.flow.flow_output) and torch.equal(am, b.covisibility.mask), (shape, mode)
+
+
 def test_two_stream_micro_batches_are_repeatable_at_benchmark_batch(env):
     """bench.py's workload itself (UFM-Base, 8 pairs at 518^2 = two concurrent micro-batches of 4): two identical calls
     agree bit for bit and pairs 0 / 4 / 7 equal their one-pair runs.  (A workgroup's first attention unit used to be

@@ -46,7 +46,11 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void conv_x3_kernel(ConvX3Arg
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntn = p.Cout / BN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tmi = bid / ntn, tni = bid - tmi * ntn;
+    const int tmi_all = bid / ntn, tni = bid - tmi_all * ntn;
+    int grp, tmi;
+    conv_x3_group_of(p, tmi_all, (p.M - p.m_begin + BM - 1) / BM, grp, tmi);
+    const uint16_t* const in_g = p.in + (size_t)grp * p.in_group;
+    const uint16_t* const w_g = p.w + (size_t)grp * p.w_group;
     const int m0 = p.m_begin + tmi * BM, n0 = tni * BN;
     const int cpt = p.Cin / BK;
     const int ntaps = p.KH * p.KW;
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void conv_x3_kernel(ConvX3Arg
 #pragma unroll
     for (int i = 0; i < W_PIECES; ++i) {
         const int r = (BN >= 64 ? wave * W_ROWS_PER_WAVE : wave * 16) + i * 16 + srow;
-        gw[i] = p.w + (size_t)(n0 + min(r, BN - 1)) * ktot + (slot ^ swz(r)) * 8;
+        gw[i] = w_g + (size_t)(n0 + min(r, BN - 1)) * ktot + (slot ^ swz(r)) * 8;
     }
     const int w_lds_row0 = (BN >= 64 ? wave * W_ROWS_PER_WAVE : wave * 16);
 
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void conv_x3_kernel(ConvX3Arg
             int iy = a_iy0[i] + kh, ix = a_ix0[i] + kw;
             if (p.replicate) iy = min(max(iy, 0), p.H - 1), ix = min(max(ix, 0), p.W - 1);
             const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const uint16_t* src = ok ? p.in + (a_img[i] + (size_t)iy * p.W + ix) * p.Cin + c0 + a_chunk[i] : p.zero + a_chunk[i];
+            const uint16_t* src = ok ? in_g + (a_img[i] + (size_t)iy * p.W + ix) * p.Cin + c0 + a_chunk[i] : p.zero + a_chunk[i];
             const uint16_t* src_lo = ok ? src + p.in_plane : src;
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(sa + i * 1024), 16, 0, 0);
             if (PASSES == 3) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src_lo), LDS_PTR(sa + A_PLANE + i * 1024), 16, 0, 0);
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void conv_x3_kernel(ConvX3Arg
 
     // ---- epilogue, staged through LDS (conv_x3_common.h): each wave parks its tile in its own slice of the idle staging buffer ----
     __syncthreads();  // all waves are done with the operand stages
-    conv_x3_epilogue<TM, TN>(p, acc, smem + wave * (TM * 16 * TN * 64), m0 + wm * (TM * 16), n0 + wn * (TN * 16), lane);
+    conv_x3_epilogue<TM, TN>(p, acc, smem + wave * (TM * 16 * TN * 64), m0 + wm * (TM * 16), n0 + wn * (TN * 16), lane, grp);
 }
 
 }  // namespace
@@ -203,15 +207,16 @@ static void launch_conv_x3(const ConvX3Args& p, int passes, hipStream_t stream) 
     // Kernel choice.  Cout % 256 == 0 and a grid that fills the chip: the 256x256 8-phase kernel on the leading pixels
     // that make whole rounds of 256 CUs, the 128-row kernel on the rest (g_conv_variant: 0 auto, 1 = 128-row kernels
     // only, 2 = 8-phase on everything it accepts -- tests/tools).
+    const int G = p.groups;
     auto launch128 = [&](const ConvX3Args& q) {
         const long long Mq = q.M - q.m_begin;
-        const int ntm = (int)((Mq + 127) / 128);
+        const int ntm = (int)((Mq + 127) / 128) * G;  // row tiles of all groups (128-row kernels; the 64-row grids below scale the same way)
         const long long blocks128 = (long long)ntm * (Cout % 128 == 0 ? Cout / 128 : Cout % 64 == 0 ? Cout / 64 : Cout / 32);
         // small grid: 64x64 tiles, several co-resident blocks per CU.  Threshold from an end-to-end sweep (400 / 200 / 100:
         // 189.6 / 196.6 / 197.2 pairs/s with two micro-batches): at 128..400 blocks the 128-row tiles win
         if (passes == 1) {  // plain bf16: the two-stage kernels only
             if (Cout % 64 == 0 && blocks128 < 128)
-                hipLaunchKernelGGL((conv_x3_kernel<64, 64, 2, 1>), dim3((unsigned)(((Mq + 63) / 64) * (Cout / 64))), dim3(256), 0, stream, q);
+                hipLaunchKernelGGL((conv_x3_kernel<64, 64, 2, 1>), dim3((unsigned)(((Mq + 63) / 64) * G * (Cout / 64))), dim3(256), 0, stream, q);
             else if (Cout % 128 == 0)
                 hipLaunchKernelGGL((conv_x3_kernel<128, 128, 2, 1>), dim3(ntm * (Cout / 128)), dim3(256), 0, stream, q);
             else if (Cout % 64 == 0)
@@ -221,7 +226,7 @@ static void launch_conv_x3(const ConvX3Args& p, int passes, hipStream_t stream) 
             return;
         }
         if (Cout % 64 == 0 && blocks128 < 128) {
-            const unsigned grid = (unsigned)(((Mq + 63) / 64) * (Cout / 64));
+            const unsigned grid = (unsigned)(((Mq + 63) / 64) * G * (Cout / 64));
             // measured per layer (tools/conv_breakdown.py): the deep ring pays on long K loops only (19^2 768->256: 138 -> 102 us;
             // short loops lose 2-3 us to its prologue), and not at all on the 128x128 tile (37^2 RCU: 68 -> 83 us)
             if (grid <= 512 && KH * KW * (Cin / 32) >= 64 && g_conv_variant != 3)
@@ -239,7 +244,7 @@ static void launch_conv_x3(const ConvX3Args& p, int passes, hipStream_t stream) 
     // 8-phase tile: 256 px x 256 cout (Cout % 256 == 0)
     const int tile_n = 256, tile_m = 256;
     const bool ok8 = Cout % 256 == 0 && KH * KW * (Cin / 32) >= 2 && p.in_plane < (1ll << 31) && p.w_plane < (1ll << 31);
-    const long long t8 = ((M + tile_m - 1) / tile_m) * (Cout / tile_n);
+    const long long t8 = ((M + tile_m - 1) / tile_m) * (Cout / tile_n) * G;  // 8-phase tiles of all groups
     if (passes == 1) {
         launch128(p);
     } else if (ok8 && g_conv_variant == 2) {
@@ -251,7 +256,7 @@ static void launch_conv_x3(const ConvX3Args& p, int passes, hipStream_t stream) 
         // fewer than 16 K-tiles (1x1 layers) the 8-phase prologue and drain cost more than its loop gains (110 vs 122-130 us).
         const long long ncu = ufm_device_cu_count();
         const long long full = t8 / ncu;                                 // whole rounds of the 8-phase kernel
-        const long long m_main = full * ncu / (Cout / tile_n) * tile_m;  // leading pixels whose tiles fit in them
+        const long long m_main = full * ncu / ((long long)(Cout / tile_n) * G) * tile_m;  // leading pixels (of every group) whose tiles fit in them
         if (m_main >= M || t8 - full * ncu >= ncu / 2) {
             ufm_launch_conv_x3_8ph(p, stream);
         } else {
@@ -270,7 +275,17 @@ extern "C" int ufm_conv2d_nhwc_bf16x3(const uint16_t* in, int B, int H, int W, i
                                       int KH, int KW, int stride, int pad, int relu_in, const float* bias, int act,
                                       const uint16_t* res1, const uint16_t* res2, int shuffle, uint16_t* out,
                                       uint16_t* out_relu, const uint16_t* zero_page, int passes, void* stream) {
+    return ufm_conv2d_nhwc_bf16x3_grouped(in, 1, 0, B, H, W, Cin, weight, Cout, KH, KW, stride, pad, relu_in, bias, act, res1, res2, shuffle, out, out_relu,
+                                          zero_page, passes, stream);
+}
+
+// `groups` convolutions of identical geometry in one launch (conv_x3_common.h ConvX3Args): the two DPT heads.
+extern "C" int ufm_conv2d_nhwc_bf16x3_grouped(const uint16_t* in, int groups, int in_shared, int B, int H, int W, int Cin, const uint16_t* weight,
+                                              int Cout, int KH, int KW, int stride, int pad, int relu_in, const float* bias, int act,
+                                              const uint16_t* res1, const uint16_t* res2, int shuffle, uint16_t* out,
+                                              uint16_t* out_relu, const uint16_t* zero_page, int passes, void* stream) {
     UFM_REQUIRE(in && weight && out && zero_page, "ufm_conv2d_nhwc_bf16x3: null pointer");
+    UFM_REQUIRE(groups >= 1 && groups <= 64, "ufm_conv2d_nhwc_bf16x3: groups=%d out of range", groups);
     UFM_REQUIRE(passes == 3 || passes == 1, "ufm_conv2d_nhwc_bf16x3: passes=%d must be 3 (bf16x3) or 1 (plain bf16)", passes);
     UFM_REQUIRE(B > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, "ufm_conv2d_nhwc_bf16x3: bad geometry");
     UFM_REQUIRE(Cin % BK == 0 && Cin > 0, "ufm_conv2d_nhwc_bf16x3: Cin=%d must be a multiple of %d", Cin, BK);
@@ -286,13 +301,17 @@ extern "C" int ufm_conv2d_nhwc_bf16x3(const uint16_t* in, int B, int H, int W, i
         UFM_REQUIRE(Co % 4 == 0, "ufm_conv2d_nhwc_bf16x3: Co=%d must be a multiple of 4 in shuffle mode", Co);
         UFM_REQUIRE(!res1 && !res2 && !out_relu && act == UFM_ACT_NONE, "ufm_conv2d_nhwc_bf16x3: shuffle mode supports bias only");
     }
-    const long long M = (long long)B * Ho * Wo;
-    UFM_REQUIRE(M < (1ll << 31), "ufm_conv2d_nhwc_bf16x3: problem too large");
-    const long long Mout = shuffle ? M * shuffle * shuffle : M;
+    const long long M = (long long)B * Ho * Wo;  // output pixels PER GROUP
+    UFM_REQUIRE(M * groups < (1ll << 31), "ufm_conv2d_nhwc_bf16x3: problem too large");
+    const long long Mout = (shuffle ? M * shuffle * shuffle : M) * groups;
+    const long long in_imgs = in_shared ? B : (long long)B * groups;
     ConvX3Args p{in, weight, bias, res1, res2, zero_page, out, out_relu,
-                 (long long)B * H * W * Cin, (long long)Cout * KH * KW * Cin, Mout * Co,
+                 in_imgs * H * W * Cin, (long long)groups * Cout * KH * KW * Cin, Mout * Co,
                  B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, (int)M, relu_in & 1, act, shuffle, Co, 0};
     p.replicate = (relu_in >> 1) & 1;
+    p.groups = groups, p.Mg = (int)M;
+    p.in_group = in_shared ? 0 : (long long)B * H * W * Cin;
+    p.w_group = (long long)Cout * KH * KW * Cin;
     launch_conv_x3(p, passes, (hipStream_t)stream);
     UFM_CHECK_LAUNCH("ufm_conv2d_nhwc_bf16x3");
     return UFM_OK;
@@ -318,6 +337,7 @@ extern "C" int ufm_gemm_bf16x3(const uint16_t* A, const uint16_t* W, int M, int 
     p.gamma = gamma;
     p.res_f32 = res;
     p.out_f32 = out_dtype == UFM_F32 ? (float*)out : nullptr;
+    p.groups = 1, p.Mg = M;
     launch_conv_x3(p, 3, (hipStream_t)stream);
     UFM_CHECK_LAUNCH("ufm_gemm_bf16x3");
     return UFM_OK;

@@ -49,7 +49,11 @@ __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
 
     const int ntn = p.Cout / (WC * 64);
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tmi = bid / ntn, tni = bid - tmi * ntn;
+    const int tmi_all = bid / ntn, tni = bid - tmi_all * ntn;
+    int grp, tmi;
+    conv_x3_group_of(p, tmi_all, (p.M - p.m_begin + WR * 128 - 1) / (WR * 128), grp, tmi);
+    const uint16_t* const in_g = p.in + (size_t)grp * p.in_group;
+    const uint16_t* const w_g = p.w + (size_t)grp * p.w_group;
     const int m0 = p.m_begin + tmi * (WR * 128), n0 = tni * (WC * 64);
     const int ntaps = p.KH * p.KW;
     const int nt = ntaps * (p.Cin >> 5);
@@ -95,14 +99,14 @@ __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
                 int iy = x_iy0[H][i] + ti.kh, ix = x_ix0[H][i] + ti.kw;
                 if (p.replicate) iy = min(max(iy, 0), p.H - 1), ix = min(max(ix, 0), p.W - 1);
                 const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                const uint16_t* src = ok ? p.in + ((x_img[H][i] + (unsigned)(iy * p.W + ix)) * (unsigned)p.Cin + (unsigned)ti.c0 + x_chunk[i]) : p.zero + x_chunk[i];
+                const uint16_t* src = ok ? in_g + ((x_img[H][i] + (unsigned)(iy * p.W + ix)) * (unsigned)p.Cin + (unsigned)ti.c0 + x_chunk[i]) : p.zero + x_chunk[i];
                 const uint16_t* src_lo = ok ? src + p.in_plane : src;
                 char* dst = base + (i * 8 + wave) * 1024;
                 __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(dst), 16, 0, 0);
                 __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src_lo), LDS_PTR(dst + XPLANE), 16, 0, 0);
             }
         } else {
-            const uint16_t* src = p.w + (w_src[H] + (unsigned)(ti.tap * p.Cin + ti.c0));
+            const uint16_t* src = w_g + (w_src[H] + (unsigned)(ti.tap * p.Cin + ti.c0));
             char* dst = base + w_piece * 1024;
             if (WP == 2) {
                 __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(dst), 16, 0, 0);
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int h = 0; h < 2; ++h)
-        conv_x3_epilogue<4, 4>(p, acc[h], smem + wave * 16384, m0 + wr * 128 + h * 64, n0 + wc * 64, lane);
+        conv_x3_epilogue<4, 4>(p, acc[h], smem + wave * 16384, m0 + wr * 128 + h * 64, n0 + wc * 64, lane, grp);
 }
 
 }  // namespace
@@ -252,7 +256,7 @@ int ufm_launch_conv_x3_8ph(const ConvX3Args& p, hipStream_t stream) {
     // 256 px x 256 cout tiles (wave layout 2 x 4).  The kernel is templated on the wave layout; the 4 x 2 layout (512 px x
     // 128 cout for Cout = 128) measured slower than the 128-row kernels (296^2 256->128: 1328 vs 1130 us) and is no longer
     // instantiated.
-    const int ntm = (p.M - p.m_begin + 255) / 256;
+    const int ntm = (p.M - p.m_begin + 255) / 256 * p.groups;
     hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4>), dim3(ntm * (p.Cout / 256)), dim3(512), 0, stream, p);
     return 0;
 }

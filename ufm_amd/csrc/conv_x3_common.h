@@ -20,7 +20,20 @@ struct ConvX3Args {
     const float* res_f32;  // fp32 residual [M][Cout] added after gamma (may alias out_f32) or null
     float* out_f32;        // non-null: the result is stored as fp32 [M][Cout] instead of the split planes
     int replicate;         // padding_mode='replicate': out-of-range taps read the nearest edge pixel instead of the zero page
+    // Grouped launch (ufm_conv2d_nhwc_bf16x3_grouped): `groups` independent convolutions of identical geometry in ONE grid --
+    // the two DPT heads (ufm.py:553-556, 637-642: the same graph with different weights).  Group g reads the weights at
+    // w + g * w_group, the bias at bias + g * (Co or Cout) and the input images at in + g * in_group (0: all groups share one
+    // input); its output / residual rows follow group g - 1's: row g * Mg + m of out / res1 / res2 / out_relu.  M and m_begin
+    // stay PER GROUP (rows [m_begin, M) of every group are covered by the launch).  groups = 1: Mg = rows of the one problem.
+    int groups, Mg;
+    long long in_group, w_group;
 };
+
+// tile row index over all groups -> (group, tile row inside the group); tiles_pg = row tiles per group of this launch
+static __device__ __forceinline__ void conv_x3_group_of(const ConvX3Args& p, int tmi_all, int tiles_pg, int& g, int& tmi) {
+    g = 0, tmi = tmi_all;
+    if (p.groups > 1) g = tmi_all / tiles_pg, tmi = tmi_all - g * tiles_pg;
+}
 
 static __device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
 
@@ -55,7 +68,10 @@ static __device__ __forceinline__ f32x4 split_load4(const uint16_t* hi_ptr, long
 // 128/64 B per plane, contiguous).  Chunk index XOR row keeps both the accumulator-shaped writes and the row-shaped
 // reads conflict-free.  LDS ops of one wave execute in order: no barrier between the writes and the reads.
 template <int TM, int TN>
-static __device__ __forceinline__ void conv_x3_epilogue(const ConvX3Args& p, f32x4 (&acc)[TN][TM], char* ws, int pix0, int cb0, int lane) {
+static __device__ __forceinline__ void conv_x3_epilogue(const ConvX3Args& p, f32x4 (&acc)[TN][TM], char* ws, int pix0, int cb0, int lane, int g = 0) {
+    // pix0 = first row of the tile INSIDE group g; rows of out / res* are numbered over all groups (row0 = g * Mg)
+    const float* bias_g = p.bias ? p.bias + (size_t)g * (p.shuffle ? p.Co : p.Cout) : nullptr;
+    const int row0 = g * p.Mg;
     constexpr int ROWB = TN * 64;              // bytes per staged row (fp32)
     constexpr int NCH = TN * 4;                // 16-byte chunks per row
     constexpr int LPR = NCH;                   // lanes per row on the way out
@@ -65,7 +81,7 @@ static __device__ __forceinline__ void conv_x3_epilogue(const ConvX3Args& p, f32
     for (int n = 0; n < TN; ++n) {
         const int cb = cb0 + n * 16 + fq * 4;
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bv = *(const f32x4*)(p.bias + (p.shuffle ? cb % p.Co : cb));
+        if (bias_g) bv = *(const f32x4*)(bias_g + (p.shuffle ? cb % p.Co : cb));
 #pragma unroll
         for (int m = 0; m < TM; ++m) {
             const int r = m * 16 + fr;
@@ -77,8 +93,8 @@ static __device__ __forceinline__ void conv_x3_epilogue(const ConvX3Args& p, f32
     for (int pass = 0; pass < TM * 16 / RPI; ++pass) {
         const int r = pass * RPI + orr;
         f32x4 v = *(const f32x4*)(ws + r * ROWB + ((oc ^ (r & (NCH - 1))) << 4));
-        const int pix = pix0 + r;
-        if (pix >= p.M) continue;
+        if (pix0 + r >= p.M) continue;
+        const int pix = row0 + pix0 + r;
         const int cb = cb0 + oc * 4;
         if (p.shuffle) {
             const int sx = pix % p.Wo, t = pix / p.Wo, sy = t % p.Ho, sb = t / p.Ho;

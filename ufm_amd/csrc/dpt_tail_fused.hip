@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void dpt_tail_fused_kernel(TailFusedArgs p)
 extern "C" int ufm_dpt_tail_fused(const uint16_t* in, int B, int h, int w, int Cin, const uint16_t* w2, const float* b2,
                                   int Cmid, int H, int W, const float* wt, const float* bt, int Ct,
                                   const int32_t* kind_host, const float* a_host, const float* d_host, float* out,
-                                  float* out_logits, void* stream) {
+                                  float* out_logits, int64_t in_plane, void* stream) {
     UFM_REQUIRE(in && w2 && b2 && wt && bt && out && kind_host && a_host && d_host, "ufm_dpt_tail_fused: null pointer");
     UFM_REQUIRE(Cin == CIN && Cmid == CMID, "ufm_dpt_tail_fused: built for 128 -> 32 channels, got %d -> %d", Cin, Cmid);
     UFM_REQUIRE(B > 0 && h > 1 && w > 1 && H > 1 && W > 1 && Ct >= 1 && Ct <= 8, "ufm_dpt_tail_fused: bad shape");
@@ -302,7 +302,8 @@ extern "C" int ufm_dpt_tail_fused(const uint16_t* in, int B, int h, int w, int C
                 "ufm_dpt_tail_fused: misaligned pointer");
     TailFusedArgs p{};
     p.in = in, p.w2 = w2, p.b2 = b2, p.wt = wt, p.bt = bt, p.out = out, p.out_logits = out_logits;
-    p.in_plane = (long long)B * h * w * CIN, p.w_plane = (long long)CMID * 9 * CIN;
+    UFM_REQUIRE(in_plane == 0 || in_plane >= (int64_t)B * h * w * CIN, "ufm_dpt_tail_fused: in_plane is shorter than the %d images", B);
+    p.in_plane = in_plane ? (long long)in_plane : (long long)B * h * w * CIN, p.w_plane = (long long)CMID * 9 * CIN;
     p.B = B, p.h = h, p.w = w, p.H = H, p.W = W, p.Ct = Ct;
     p.sy = (float)(h - 1) / (float)(H - 1), p.sx = (float)(w - 1) / (float)(W - 1);  // as ufm_upsample_bilinear_nhwc
     for (int c = 0; c < 8; ++c) {

@@ -187,6 +187,51 @@ class _Head:
         self.shift = [s for a in self.adaptors for s in a.shift]
 
 
+class _ConvG:
+    """The same layer of several heads stacked for ufm_conv2d_nhwc_bf16x3_grouped: weights (2, G, Cout, ...), bias (G, Cout)."""
+
+    def __init__(self, convs: List[_Conv]):
+        c0 = convs[0]
+        for c in convs[1:]:
+            assert (c.cin, c.cout, c.k, c.stride, c.pad, c.shuffle) == (c0.cin, c0.cout, c0.k, c0.stride, c0.pad, c0.shuffle) and c.w.shape == c0.w.shape
+            assert (c.b is None) == (c0.b is None)
+        self.cin, self.cout, self.k, self.stride, self.pad, self.shuffle = c0.cin, c0.cout, c0.k, c0.stride, c0.pad, c0.shuffle
+        self.groups = len(convs)
+        self.w = torch.stack([c.w for c in convs], dim=1).contiguous()
+        self.b = torch.stack([c.b for c in convs], dim=0).contiguous() if c0.b is not None else None
+
+
+class _HeadG:
+    """Several DPT heads of identical layer shapes (the flow head and the covisibility head: ufm.py:553-556) packed for one
+    grouped launch per layer; only their last stage (3x3 128 -> 32, 1x1 -> output channels, adaptors) differs and stays per head."""
+
+    def __init__(self, heads: List[_Head]):
+        h0 = heads[0]
+        self.heads = heads
+        self.groups = len(heads)
+        self.feature_dim, self.layer_dims, self.hooks = h0.feature_dim, h0.layer_dims, h0.hooks
+        self.act = [[_ConvG([h.act[i][j] for h in heads]) for j in range(len(h0.act[i]))] for i in range(4)]
+        self.rn = [_ConvG([h.rn[i] for h in heads]) for i in range(4)]
+        self.fuse = [dict(out=_ConvG([h.fuse[i]["out"] for h in heads]),
+                          r1=(_ConvG([h.fuse[i]["r1"][0] for h in heads]), _ConvG([h.fuse[i]["r1"][1] for h in heads])),
+                          r2=(_ConvG([h.fuse[i]["r2"][0] for h in heads]), _ConvG([h.fuse[i]["r2"][1] for h in heads]))) for i in range(4)]
+        self.p_conv1 = _ConvG([h.p_conv1 for h in heads])
+
+    @staticmethod
+    def compatible(heads) -> bool:
+        if len(heads) < 2 or not all(isinstance(h, _Head) for h in heads):
+            return False
+        h0 = heads[0]
+        sig = lambda c: (c.cin, c.cout, c.k, c.stride, c.pad, c.shuffle, tuple(c.w.shape), c.w.dtype, c.b is None)  # noqa: E731
+        def layers(h):
+            out = [sig(c) for seq in h.act for c in seq] + [sig(c) for c in h.rn] + [sig(h.p_conv1)]
+            for f in h.fuse:
+                out += [sig(f["out"]), sig(f["r1"][0]), sig(f["r1"][1]), sig(f["r2"][0]), sig(f["r2"][1])]
+            return out
+        return all(h.hooks == h0.hooks and h.layer_dims == h0.layer_dims and h.feature_dim == h0.feature_dim and layers(h) == layers(h0) for h in heads[1:]) \
+            and h0.p_conv1.w.dtype == torch.bfloat16
+
+
 class _MoGeHead:
     """Packed MoGeConvParams (modules.py): every convolution as a _Conv, GroupNorm affine vectors in fp32."""
 
@@ -252,6 +297,12 @@ class Engine:
         # rounding of the branch costs accuracy (flow max-abs 0.035 -> 0.041 px).  Default: off (fp32 accumulator straight
         # into the stream).
         self.defer_residual = False
+        # group_heads: DPT heads of identical layer shapes run every layer as ONE grouped launch (ufm_conv2d_nhwc_bf16x3_grouped) on a
+        # head-major stacked batch -- twice the tiles per grid instead of two launch sequences on two streams; bit-identical.
+        # OFF by default: measured same-box (round 4, profiles/r04/grouped_heads_ab.log) 215.0 vs 216.9 pairs/s at B = 8 and
+        # 9.11-9.14 vs 9.01-9.15 ms graph replay at B = 1 -- the two streams already interleave one head's small-grid layers with
+        # the other's large ones, which one serial chain of doubled grids does not
+        self.group_heads = False
         self.fused_tail = True  # ufm_dpt_tail_fused where the head has the UFM-Base tail shape (bit-identical to the unfused path)
         # DPT heads on separate HIP streams: None = automatic (yes for a single-stream forward -- one pair: 9.84 -> 8.97 ms
         # graph replay, the small-grid layers of one head fill the other's tails -- no inside a micro-batch worker, where the
@@ -302,6 +353,7 @@ class Engine:
         # DPT heads: exact-fp32 MFMA in "parity"; bf16x3 split precision (UFM_BF16X2 activations) in "fast"
         self.head_split = self.numerics in ("fast", "precise", "parity_x3heads")
         moge = not isinstance(m.head1[0], nn.Sequential)  # head_type "moge_conv" (ufm.py:266-267): one feature module, not (DPTFeature, processor)
+        self._head_group = None  # _HeadG of self.heads, packed on first use
         self.heads = {"head1": (_MoGeHead if moge else _Head)(m.head1, dev, self.head_split)}
         if hasattr(m, "uncertainty_head"):  # built with its own head type (ufm.py:553-556 passes uncertainty_head_type)
             moge_u = not isinstance(m.uncertainty_head[0], nn.Sequential)
@@ -458,10 +510,12 @@ class Engine:
             assert res_row_mod == 0 and out_row_group == 0 and out.dtype == torch.float32
             hip.conv2d(x, 1, 1, M, lin.k, lin.w, lin.n, 1, 1, 1, 0, out, self.zero, bias=lin.b, act=act, gamma=gamma, res1=res)
 
-    def conv(self, x, B, H, W, c: _Conv, out, *, relu_in=False, act=hip.ACT_NONE, res1=None, res2=None, out_relu=None, replicate=False):
+    def conv(self, x, B, H, W, c: _Conv, out, *, relu_in=False, act=hip.ACT_NONE, res1=None, res2=None, out_relu=None, replicate=False, in_shared=False):
+        """``c`` a _ConvG: the grouped launch (B = images per group; x / out / res hold groups * B images, group-major; ``in_shared``:
+        x holds B images that every group reads)."""
         if c.w.dtype == torch.bfloat16:
             hip.conv2d_x3(x, B, H, W, c.cin, c.w, c.cout, c.k, c.k, c.stride, c.pad, out, self.zero, relu_in=relu_in, bias=c.b, act=act, res1=res1, res2=res2, shuffle=c.shuffle, out_relu=out_relu,
-                          passes=getattr(c, "passes", 3), replicate=replicate)
+                          passes=getattr(c, "passes", 3), replicate=replicate, groups=getattr(c, "groups", 1), in_shared=in_shared)
         else:
             assert out_relu is None
             hip.conv2d(x, B, H, W, c.cin, c.w, c.cout, c.k, c.k, c.stride, c.pad, out, self.zero, relu_in=relu_in, bias=c.b, act=act, res1=res1, res2=res2, shuffle=c.shuffle, replicate=replicate)
@@ -619,34 +673,40 @@ class Engine:
         return x, Np, N
 
     # ------------------------------------------------------------------ DPT head
-    def _head(self, hw: _Head, tag: str, levels: List[torch.Tensor], level_dims: List[int], B: int, gh: int, gw: int, H: int, W: int):
+    def _head(self, hw, tag: str, levels: List[torch.Tensor], level_dims: List[int], B: int, gh: int, gw: int, H: int, W: int):
+        """[U] DPTFeature + DPTRegressionProcessor + adaptors on NHWC maps.  ``hw``: one packed head (_Head) -> that head's
+        adaptor outputs; or a _HeadG (several heads of identical layer shapes) -> every layer up to p_conv1 is ONE grouped launch
+        on a head-major stacked batch of G * B images, then each head's own tail on its slice; returns a list of adaptor outputs
+        in the order of ``hw.heads``.  Bit-identical either way (tests)."""
         # (Measured in round 3 and not kept: the four level chains on four HIP streams -- 37.8 vs 37.1 ms per step at B = 8,
         #  and a nested stream fork inside the two-stream head capture crashed hipGraph capture at B = 1.)
+        G = getattr(hw, "groups", 1)
+        Bt = G * B  # images in every activation buffer of this call
         Fd = hw.feature_dim
         ld = hw.layer_dims
         sizes = [(4 * gh, 4 * gw), (2 * gh, 2 * gw), (gh, gw), ((gh - 1) // 2 + 1, (gw - 1) // 2 + 1)]
         r = []
         for i in range(4):
             lvl = levels[hw.hooks[i]]
-            t = self.hbuf(f"{tag}_act{i}", (B, gh, gw, ld[i]))
-            self.conv(lvl, B, gh, gw, hw.act[i][0], t)
+            t = self.hbuf(f"{tag}_act{i}", (Bt, gh, gw, ld[i]))
+            self.conv(lvl, B, gh, gw, hw.act[i][0], t, in_shared=G > 1)  # every head reads the same pyramid level
             u = t
             if i < 2 or i == 3:
-                u = self.hbuf(f"{tag}_post{i}", (B, sizes[i][0], sizes[i][1], ld[i]))
+                u = self.hbuf(f"{tag}_post{i}", (Bt, sizes[i][0], sizes[i][1], ld[i]))
                 self.conv(t, B, gh, gw, hw.act[i][1], u)
-            ri = self.hbuf(f"{tag}_rn{i}", (B, sizes[i][0], sizes[i][1], Fd))
+            ri = self.hbuf(f"{tag}_rn{i}", (Bt, sizes[i][0], sizes[i][1], Fd))
             # split mode: the producer of an RCU input also writes relu(x) (ufm_conv2d_nhwc_bf16x3 out_relu), which takes
             # the ReLU out of the consumer's MFMA loop; the fp32 kernels apply it on their fragments (relu_in)
-            rr = self.hbuf(f"{tag}_rn{i}_relu", (B, sizes[i][0], sizes[i][1], Fd)) if self.head_split else None
+            rr = self.hbuf(f"{tag}_rn{i}_relu", (Bt, sizes[i][0], sizes[i][1], Fd)) if self.head_split else None
             self.conv(u, B, sizes[i][0], sizes[i][1], hw.rn[i], ri, out_relu=rr)
             r.append((ri, rr))
 
         def rcu(xs, pair, h, w, name, extra_res=None, want_relu=False):
             """[U] ResidualConvUnit: conv2(relu(conv1(relu(x)))) + x (+ extra_res).  xs = (x, relu(x) or None)."""
             x, xr = xs
-            t1 = self.hbuf(f"{tag}_{name}_t", (B, h, w, Fd))
-            o = self.hbuf(f"{tag}_{name}_o", (B, h, w, Fd))
-            orl = self.hbuf(f"{tag}_{name}_or", (B, h, w, Fd)) if (want_relu and self.head_split) else None
+            t1 = self.hbuf(f"{tag}_{name}_t", (Bt, h, w, Fd))
+            o = self.hbuf(f"{tag}_{name}_o", (Bt, h, w, Fd))
+            orl = self.hbuf(f"{tag}_{name}_or", (Bt, h, w, Fd)) if (want_relu and self.head_split) else None
             if self.head_split:
                 self.conv(xr, B, h, w, pair[0], t1, act=hip.ACT_RELU)  # relu applied once, by the producers
                 self.conv(t1, B, h, w, pair[1], o, res1=x, res2=extra_res, out_relu=orl)
@@ -665,23 +725,32 @@ class Engine:
                 s = rcu(r[lvl], f["r1"], h, w, f"f{lvl}a", extra_res=path, want_relu=True)  # path + resConfUnit1(r)
             o, _ = rcu(s, f["r2"], h, w, f"f{lvl}b")
             # out_conv (1x1) commutes with the bilinear x2 (weights sum to 1): run it at low resolution
-            c = self.hbuf(f"{tag}_f{lvl}c", (B, h, w, Fd))
+            c = self.hbuf(f"{tag}_f{lvl}c", (Bt, h, w, Fd))
             self.conv(o, B, h, w, f["out"], c)
             if lvl == 3:
                 th, tw = sizes[2]  # refinenet4 output is cropped to layer-3's grid
-                path = self.hbuf(f"{tag}_p{lvl}", (B, th, tw, Fd))
-                hip.upsample_bilinear(c, B, h, w, Fd, path, 2 * h, 2 * w, th, tw)
+                path = self.hbuf(f"{tag}_p{lvl}", (Bt, th, tw, Fd))
+                hip.upsample_bilinear(c, Bt, h, w, Fd, path, 2 * h, 2 * w, th, tw)
             else:
-                path = self.hbuf(f"{tag}_p{lvl}", (B, 2 * h, 2 * w, Fd))
-                hip.upsample_bilinear(c, B, h, w, Fd, path, 2 * h, 2 * w)
+                path = self.hbuf(f"{tag}_p{lvl}", (Bt, 2 * h, 2 * w, Fd))
+                hip.upsample_bilinear(c, Bt, h, w, Fd, path, 2 * h, 2 * w)
         h8, w8 = 2 * sizes[0][0], 2 * sizes[0][1]
-        c1 = self.hbuf(f"{tag}_pc1", (B, h8, w8, hw.p_conv1.cout))
+        c1 = self.hbuf(f"{tag}_pc1", (Bt, h8, w8, hw.p_conv1.cout))
         self.conv(path, B, h8, w8, hw.p_conv1, c1)
+        if G > 1:  # each head's own tail on its B images of the stacked p_conv1 output (callers checked _tail_fusable for every head)
+            plane = Bt * h8 * w8 * hw.p_conv1.cout
+            results = []
+            for g, hh in enumerate(hw.heads):
+                out = torch.empty((B, hh.tail_cout, H, W), device=self.dev, dtype=torch.float32)
+                logits = torch.empty_like(out) if 1 in hh.kinds else None
+                hip.dpt_tail_fused(c1[0][g * B : (g + 1) * B], B, h8, w8, 128, hh.p_conv2a.w, hh.p_conv2a.b, 32, H, W, hh.tail_w, hh.tail_b, hh.tail_cout, hh.kinds, hh.scale, hh.shift,
+                                   out, logits, in_plane=plane)
+                results.append(self._adaptor_outputs(hh, out, logits, B, H, W))
+            return results
         out = torch.empty((B, hw.tail_cout, H, W), device=self.dev, dtype=torch.float32)
         logits = torch.empty_like(out) if 1 in hw.kinds else None
         c2a = hw.p_conv2a
-        up_ok = h8 <= H and w8 <= W and max((h8 - 1) / (H - 1), (w8 - 1) / (W - 1)) * 17 + 2 <= 13  # the kernel's halo-row budget
-        if self.fused_tail and self.head_split and up_ok and (c2a.cin, c2a.cout, c2a.k, c2a.stride, c2a.pad, hw.tail_cin) == (128, 32, 3, 1, 1, 32):
+        if self._tail_fusable(hw, gh, gw, H, W):
             # upsample -> conv3x3 + ReLU -> conv1x1 -> adaptor in one kernel: the two full-resolution maps stay on chip
             hip.dpt_tail_fused(c1, B, h8, w8, 128, c2a.w, c2a.b, 32, H, W, hw.tail_w, hw.tail_b, hw.tail_cout, hw.kinds, hw.scale, hw.shift, out, logits)
         else:
@@ -691,6 +760,13 @@ class Engine:
             self.conv(up, B, H, W, c2a, c2, act=hip.ACT_RELU)
             hip.head_tail(c2, B * H * W, H * W, hw.tail_cin, hw.tail_w, hw.tail_b, hw.tail_cout, hw.kinds, hw.scale, hw.shift, out, logits)
         return self._adaptor_outputs(hw, out, logits, B, H, W)
+
+    def _tail_fusable(self, hw: _Head, gh: int, gw: int, H: int, W: int) -> bool:
+        """ufm_dpt_tail_fused applies: split-format heads, the UFM-Base tail shape, an up-sampling ratio inside its halo-row budget."""
+        h8, w8 = 8 * gh, 8 * gw
+        c2a = hw.p_conv2a
+        up_ok = h8 <= H and w8 <= W and H > 1 and W > 1 and max((h8 - 1) / (H - 1), (w8 - 1) / (W - 1)) * 17 + 2 <= 13
+        return bool(self.fused_tail and self.head_split and up_ok and (c2a.cin, c2a.cout, c2a.k, c2a.stride, c2a.pad, hw.tail_cin) == (128, 32, 3, 1, 1, 32))
 
     def _adaptor_outputs(self, hw, out, logits, B: int, H: int, W: int):
         """Split the decoded channels between the adaptors ([U] AdaptorMap; ufm.py:644-660)."""
@@ -1070,8 +1146,20 @@ class Engine:
                 return self._head_moge(hw, tag, levels, B, gh, gw, H, W)
             return self._head(hw, tag, levels, dims, B, gh, gw, H, W)
 
-        conc = self.concurrent_heads if self.concurrent_heads is not None else getattr(self._tls, "ns", "") == ""
-        if len(self.heads) > 1 and conc and hip.TIMER is None:
+        hlist = list(self.heads.values())
+        if (self.group_heads and len(hlist) > 1 and self.head_split and _HeadG.compatible(hlist) and hlist[0].p_conv1.cout == 128
+                and all(self._tail_fusable(h, gh, gw, H, W) for h in hlist)):
+            # the heads are the same graph with different weights (ufm.py:553-556, 637-642): one grouped launch per layer
+            if self._head_group is None:
+                self._head_group = _HeadG(hlist)
+            for tag, res in zip(self.heads.keys(), self._head(self._head_group, "hg", levels, dims, B, gh, gw, H, W)):
+                out[tag] = res
+            conc = None
+        else:
+            conc = self.concurrent_heads if self.concurrent_heads is not None else getattr(self._tls, "ns", "") == ""
+        if conc is None:
+            pass
+        elif len(self.heads) > 1 and conc and hip.TIMER is None:
             # the heads only share their (read-only) input pyramid: run them on separate HIP streams so the
             # latency-bound small-grid layers of one overlap the large layers of the other
             main = torch.cuda.current_stream(self.dev)

@@ -44,7 +44,7 @@ SIGNATURES = {
     "ufm_debug_set_conv_variant": [_i],
     "ufm_debug_set_upsample_variant": [_i],
     "ufm_warp_bilinear": [_vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _f, _vp, _vp],
-    "ufm_dpt_tail_fused": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ufm_dpt_tail_fused": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "ufm_layernorm": [_vp, _i, _vp, _i, _i, _vp, _vp, _f, _vp, _i, _i, _vp],
     "ufm_layernorm_slice": [_vp, _i, _vp, _i, _i, _vp, _vp, _f, _vp, _i, _i, _i64, _vp],
     "ufm_add_layernorm": [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _f, _vp, _i, _i, _vp],
@@ -56,6 +56,7 @@ SIGNATURES = {
     "ufm_debug_attention_stamps": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "ufm_conv2d_nhwc_f32": [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp],
     "ufm_conv2d_nhwc_bf16x3": [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp],
+    "ufm_conv2d_nhwc_bf16x3_grouped": [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp],
     "ufm_gemm_bf16x3": [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "ufm_attention_bf16x3": [_vp, _vp, _i, _i, _i, _f, _vp],
     "ufm_upsample_bilinear_nhwc": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp],
@@ -299,11 +300,22 @@ def conv2d(x, B, H, W, Cin, weight, Cout, KH, KW, stride, pad, out, zero_page, *
     )
 
 
-def conv2d_x3(x, B, H, W, Cin, weight, Cout, KH, KW, stride, pad, out, zero_page, *, relu_in=False, bias=None, act=ACT_NONE, res1=None, res2=None, shuffle=0, out_relu=None, passes=3, replicate=False):
+def conv2d_x3(x, B, H, W, Cin, weight, Cout, KH, KW, stride, pad, out, zero_page, *, relu_in=False, bias=None, act=ACT_NONE, res1=None, res2=None, shuffle=0, out_relu=None, passes=3, replicate=False,
+              groups=1, in_shared=False):
     """bf16x3 split-precision conv; x / weight / res / out are (2, ...) bf16 tensors (UFM_BF16X2).
-    passes=1: the hi planes only (a plain bf16 convolution with fp32 accumulation), same operand and output format."""
+    passes=1: the hi planes only (a plain bf16 convolution with fp32 accumulation), same operand and output format.
+    groups > 1: that many convolutions of identical geometry in one launch (ufm_conv2d_nhwc_bf16x3_grouped); B is per group."""
     Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
-    _t("ufm_conv2d_nhwc_bf16x3" if passes == 3 else "ufm_conv2d_nhwc_bf16x1", 2.0 * B * Ho * Wo * Cout * KH * KW * Cin)
+    if groups > 1:
+        _t("ufm_conv2d_nhwc_bf16x3", (2.0 * groups * B * Ho * Wo * Cout * KH * KW * Cin, f"G{groups} B{B} {H}x{W} {Cin}->{Cout} k{KH}" + (f" s{stride}" if stride != 1 else "") + (f" shuffle{shuffle}" if shuffle else "")))
+        _check(
+            lib().ufm_conv2d_nhwc_bf16x3_grouped(_p(x), groups, int(in_shared), B, H, W, Cin, _p(weight), Cout, KH, KW, stride, pad, int(relu_in) | (2 if replicate else 0), _p(bias), act, _p(res1), _p(res2),
+                                                 shuffle, _p(out), _p(out_relu), _p(zero_page), passes, _stream()),
+            "ufm_conv2d_nhwc_bf16x3",  # (the timer's family name; the entry point is ufm_conv2d_nhwc_bf16x3_grouped)
+        )
+        return
+    _t("ufm_conv2d_nhwc_bf16x3" if passes == 3 else "ufm_conv2d_nhwc_bf16x1",
+       (2.0 * B * Ho * Wo * Cout * KH * KW * Cin, f"B{B} {H}x{W} {Cin}->{Cout} k{KH}" + (f" s{stride}" if stride != 1 else "") + (f" shuffle{shuffle}" if shuffle else "")))
     _check(
         lib().ufm_conv2d_nhwc_bf16x3(_p(x), B, H, W, Cin, _p(weight), Cout, KH, KW, stride, pad, int(relu_in) | (2 if replicate else 0), _p(bias), act, _p(res1), _p(res2), shuffle, _p(out), _p(out_relu), _p(zero_page), passes, _stream()),
         "ufm_conv2d_nhwc_bf16x3",
@@ -320,10 +332,11 @@ def head_tail(x, P, HW, Cin, w, b, Cout, kinds, a, d, out, out_logits=None):
     _check(lib().ufm_head_tail(_p(x), BF16X2 if x.dtype == torch.bfloat16 else F32, P, HW, Cin, _p(w), _p(b), Cout, _i4(kinds), _f3(a), _f3(d), _p(out), _p(out_logits), _stream()), "ufm_head_tail")
 
 
-def dpt_tail_fused(x, B, h, w, Cin, w2, b2, Cmid, H, W, wt, bt, Ct, kinds, a, d, out, out_logits=None):
-    """upsample -> conv3x3 + ReLU -> conv1x1 -> adaptor in one kernel (split-bf16 input and 3x3 weights)."""
+def dpt_tail_fused(x, B, h, w, Cin, w2, b2, Cmid, H, W, wt, bt, Ct, kinds, a, d, out, out_logits=None, in_plane=0):
+    """upsample -> conv3x3 + ReLU -> conv1x1 -> adaptor in one kernel (split-bf16 input and 3x3 weights).
+    in_plane: elements between the hi and lo plane of x when x is one head's slice of a stacked buffer (0 = dense)."""
     _t("ufm_dpt_tail_fused", 2.0 * B * H * W * Cmid * 9 * Cin)
-    _check(lib().ufm_dpt_tail_fused(_p(x), B, h, w, Cin, _p(w2), _p(b2), Cmid, H, W, _p(wt), _p(bt), Ct, _i4(kinds), _f3(a), _f3(d), _p(out), _p(out_logits), _stream()), "ufm_dpt_tail_fused")
+    _check(lib().ufm_dpt_tail_fused(_p(x), B, h, w, Cin, _p(w2), _p(b2), Cmid, H, W, _p(wt), _p(bt), Ct, _i4(kinds), _f3(a), _f3(d), _p(out), _p(out_logits), int(in_plane), _stream()), "ufm_dpt_tail_fused")
 
 
 def warp_bilinear(target, flow, out, mask=None, mask_mode=0, fill=0.0):
