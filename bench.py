@@ -203,6 +203,7 @@ def main():
     ap.add_argument("--rope", type=float, default=0.0, help="with --info-sharing cross_attention: RoPE-2D base frequency (0 = none)")
     ap.add_argument("--head", default="dpt", choices=["dpt", "moge_conv"], help="side measurement (SURVEY 8(f)4): the MoGe convolutional flow head (ufm.py:266-267)")
     ap.add_argument("--group-heads", type=int, default=0, help="1: the two DPT heads as one grouped launch per layer (Engine.group_heads; measured 1 %% slower than the default two launch sequences on two streams)")
+    ap.add_argument("--conv-splitk", type=int, default=0, help="1: deterministic split-K in the heads' small-map convolutions (Engine.conv_splitk; measured neutral)")
     ap.add_argument("--last-layer-view1", type=int, default=1, help="0: the last joint-attention block on all rows (A/B of Engine.last_layer_view1)")
     ap.add_argument("--micro-batches", type=int, default=2, help="concurrent micro-batches (HIP streams) per GPU; 1 = single stream")
     args = ap.parse_args()
@@ -257,6 +258,7 @@ def main():
     model.engine().micro_batches = args.micro_batches
     model.engine().last_layer_view1 = bool(args.last_layer_view1)
     model.engine().group_heads = bool(args.group_heads)
+    model.engine().conv_splitk = bool(args.conv_splitk)
     if args.concurrent_heads >= 0:
         model.engine().concurrent_heads = bool(args.concurrent_heads)
 

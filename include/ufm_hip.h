@@ -268,7 +268,15 @@ int ufm_conv2d_nhwc_bf16x3(const uint16_t* in, int B, int H, int W, int Cin, con
 int ufm_conv2d_nhwc_bf16x3_grouped(const uint16_t* in, int groups, int in_shared, int B, int H, int W, int Cin,
                                    const uint16_t* weight, int Cout, int KH, int KW, int stride, int pad, int relu_in,
                                    const float* bias, int act, const uint16_t* res1, const uint16_t* res2, int shuffle,
-                                   uint16_t* out, uint16_t* out_relu, const uint16_t* zero_page, int passes, void* stream);
+                                   uint16_t* out, uint16_t* out_relu, const uint16_t* zero_page, int passes,
+                                   void* splitk_ws /* may be NULL */, long long splitk_ws_bytes, void* stream);
+/* Deterministic split-K.  With a workspace (zero-filled when allocated; the kernel leaves its counters zero again) the K loop of
+ * the small-map, long-K layers (<= 1600 output pixels per image and >= 48 K-tiles of 32 channels: the 19^2 / 37^2 layers of the DPT
+ * heads) is cut into 2-6 consecutive ranges, one workgroup each; fp32 partial tiles meet in the workspace and the last workgroup
+ * of a tile adds them in range order and runs the epilogue.  The factor depends on the layer's geometry only -- not on B or
+ * groups -- so a pixel's bits do not depend on the batch it is computed in; they DO differ (in the last bits) from the same
+ * layer without a workspace.  One workspace per stream.  Size: ufm_conv_x3_splitk_ws_bytes (0 = this layer is never split). */
+long long ufm_conv_x3_splitk_ws_bytes(int groups, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 
 /* =====================================================================================
  * Numerics mode "precise": the transformer trunk on the split format (fp32-class accuracy at bf16 MFMA rates / 3).

@@ -1167,6 +1167,62 @@ def test_conv2d_bf16x3_grouped_is_bitwise_the_separate_launches(hip, B, H, W, Ci
         assert torch.equal(orl.view(torch.int16), cat(want_r).view(torch.int16))
 
 
+@pytest.mark.parametrize(
+    "H,W,Cin,Cout,k,stride,pad,nres",
+    [
+        (19, 19, 768, 256, 3, 1, 1, 0),   # 216 K-tiles -> 6 slices (layer_rn of the coarsest level)
+        (37, 37, 256, 256, 3, 1, 1, 2),   # 72 K-tiles -> 3 slices, residuals + relu output (the 37^2 RCUs)
+        (37, 37, 768, 768, 3, 2, 1, 0),   # stride 2 down to 19^2 (act_4_postprocess)
+        (37, 37, 384, 256, 3, 1, 1, 0),   # 108 K-tiles -> 4 slices
+        (21, 23, 96, 64, 3, 1, 1, 1),     # 27 K-tiles: below the threshold, the workspace must be left untouched
+    ],
+)
+def test_conv2d_bf16x3_split_k_is_deterministic_and_batch_invariant(hip, H, W, Cin, Cout, k, stride, pad, nres):
+    """Split-K of the small-map long-K layers (ufm_conv2d_nhwc_bf16x3_grouped with a workspace): (1) equals the unsplit kernel
+    to fp32 re-association (2) repeated launches agree bit for bit (fixed range order, whoever arrives last) (3) an image's
+    result is the same bits at batch 1 and inside a batch of 5 and inside a 2-group launch -- the split factor depends on the
+    layer's geometry only (4) the tile counters are back at zero."""
+    lib = hip.lib()
+    B = 5
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    x = split(nhwc(rnd(B, Cin, H, W, seed=1))).to(DEV)
+    w = split(rnd(Cout, k, k, Cin, seed=2, scale=(Cin * k * k) ** -0.5)).to(DEV)
+    b = rnd(Cout, seed=3, scale=0.1).to(DEV)
+    res = [split(rnd(B, Ho, Wo, Cout, seed=10 + i)).to(DEV) for i in range(nres)] + [None, None]
+    zero = torch.zeros(256, device=DEV)
+    need = lib.ufm_conv_x3_splitk_ws_bytes(2, B, H, W, Cin, Cout, k, k, stride, pad)
+    expect_split = Ho * Wo <= 1600 and k * k * (Cin // 32) >= 48
+    assert (need > 0) == expect_split
+    ws = torch.zeros(max(need, 1 << 16) // 4, device=DEV, dtype=torch.float32)
+
+    def run(xx, bb, r, nb, groups=1, ww=w, use_ws=True):
+        out = torch.full((2, groups * nb, Ho, Wo, Cout), 7.0, device=DEV, dtype=torch.bfloat16)
+        orl = torch.full_like(out, 7.0)
+        hip.conv2d_x3(xx, nb, H, W, Cin, ww, Cout, k, k, stride, pad, out, zero, bias=bb, res1=r[0], res2=r[1], out_relu=orl, groups=groups, splitk_ws=ws if use_ws else None)
+        return out, orl
+
+    plain, _ = run(x, b, res, B, use_ws=False)
+    a, ar = run(x, b, res, B)
+    assert float(ws[: 1 << 14].abs().max()) == 0.0  # counters (the first 64 KiB) are zero again
+    if not expect_split:
+        assert torch.equal(a, plain) and float(ws.abs().max()) == 0.0
+        return
+    err = (unsplit(a.cpu()) - unsplit(plain.cpu())).abs().max().item()
+    # a different summation order, nothing more: a few units of the split format's own resolution (2^-17 relative)
+    assert 0 < err <= 4e-5 * max(1.0, unsplit(plain.cpu()).abs().max().item()), err
+    for _ in range(3):
+        a2, ar2 = run(x, b, res, B)
+        assert torch.equal(a2, a) and torch.equal(ar2, ar)
+    for i in (0, 3):  # one image alone == the same image inside the batch
+        one, _ = run(x[:, i : i + 1].contiguous(), b, [r[:, i : i + 1].contiguous() if r is not None else None for r in res], 1)
+        assert torch.equal(one[:, 0], a[:, i])
+    # two groups (the second with other weights): group 0 == the ungrouped launch
+    w2 = split(rnd(Cout, k, k, Cin, seed=5, scale=(Cin * k * k) ** -0.5)).to(DEV)
+    cat = lambda t: torch.cat([t, t], dim=1).contiguous() if t is not None else None  # noqa: E731
+    g, _ = run(cat(x), torch.stack([b, b * 2]), [cat(r) for r in res], B, groups=2, ww=torch.stack([w, w2], dim=1).contiguous())
+    assert torch.equal(g[:, :B], a)
+
+
 @pytest.mark.parametrize("s,Cin,Co", [(4, 32, 32), (2, 64, 48)])
 def test_conv_transpose_bf16x3(hip, s, Cin, Co):
     B, H, W = 2, 5, 7

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-pair (and two-pair) p50 latency, UFM-Base 518^2, hipGraph replay and eager: A/B of Engine.group_heads (the two DPT heads as
-one grouped launch per layer vs two launch sequences on two streams) in one process, interleaved."""
+one grouped launch per layer vs two launch sequences on two streams) or, with --splitk, of Engine.conv_splitk; one process, interleaved."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import ufm_amd
@@ -22,10 +22,13 @@ for B in (1, 2, 3):
     outs = {}
     for rep in range(2):
         for gh in (True, False):
-            m.engine().group_heads = gh
+            if '--splitk' in sys.argv:
+                m.engine().conv_splitk = gh
+            else:
+                m.engine().group_heads = gh
             outs[gh] = m.predict_correspondences_batched(src, tgt).flow.flow_output.clone()
             e = p50(lambda: m.predict_correspondences_batched(src, tgt))
             gp = ufm_amd.GraphedPredictor(m, src, tgt)
             r = p50(lambda: gp(src, tgt))
-            print(f"B={B} group_heads={int(gh)}: eager p50 {e:.2f} ms, graph replay p50 {r:.2f} ms", flush=True)
-    print("bitwise equal:", torch.equal(outs[True], outs[False]))
+            print(f"B={B} {'conv_splitk' if '--splitk' in sys.argv else 'group_heads'}={int(gh)}: eager p50 {e:.2f} ms, graph replay p50 {r:.2f} ms", flush=True)
+    print("bitwise equal:", torch.equal(outs[True], outs[False]), "max abs diff", (outs[True] - outs[False]).abs().max().item())

@@ -45,7 +45,12 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void conv_x3_kernel(ConvX3Arg
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntn = p.Cout / BN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int slice = 0;
+    if (p.splitk > 1) {  // a tile's slices are consecutive logical ids: concurrent on one XCD, the reducer reads them from its L2
+        slice = bid % p.splitk;
+        bid /= p.splitk;
+    }
     const int tmi_all = bid / ntn, tni = bid - tmi_all * ntn;
     int grp, tmi;
     conv_x3_group_of(p, tmi_all, (p.M - p.m_begin + BM - 1) / BM, grp, tmi);
@@ -131,32 +136,36 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void conv_x3_kernel(ConvX3Arg
 #pragma unroll
         for (int m = 0; m < TM; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // K-tiles of this workgroup: all of them, or slice `slice` of `splitk` consecutive ranges (balanced, in K order)
+    const int kt0 = p.splitk > 1 ? (int)((long long)nk * slice / p.splitk) : 0;
+    const int kt1 = p.splitk > 1 ? (int)((long long)nk * (slice + 1) / p.splitk) : nk;
+    const int nkl = kt1 - kt0;
     if (NS == 2) {
-        stage(0, 0);
+        stage(0, kt0);
     } else {
 #pragma unroll
         for (int i = 0; i < NS - 1; ++i)
-            if (i < nk) stage(i, i);
+            if (i < nkl) stage(i, kt0 + i);
     }
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int it = 0; it < nkl; ++it) {
         if (NS == 2) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+            if (it + 1 < nkl) stage((it + 1) & 1, kt0 + it + 1);
         } else {
-            // K-tile kt has landed once at most the DMA pieces of the younger tiles (<= NS - 2 of them) are outstanding.
+            // K-tile `it` has landed once at most the DMA pieces of the younger tiles (<= NS - 2 of them) are outstanding.
             // RAW: every wave waits for its own pieces, then the barrier.  WAR: the slot restaged below was last read in
-            // iteration kt - 1, whose fragment reads every wave has retired (lgkmcnt(0) before its MFMAs) before this barrier.
-            const int younger = min(NS - 2, nk - 1 - kt);
+            // iteration it - 1, whose fragment reads every wave has retired (lgkmcnt(0) before its MFMAs) before this barrier.
+            const int younger = min(NS - 2, nkl - 1 - it);
             if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
             else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if (kt + NS - 1 < nk) stage((kt + NS - 1) % NS, kt + NS - 1);
+            if (it + NS - 1 < nkl) stage((it + NS - 1) % NS, kt0 + it + NS - 1);
         }
-        const char* s = smem + (kt % NS) * STAGE_BYTES;
+        const char* s = smem + (it % NS) * STAGE_BYTES;
         bf16x8 ah[TM], al[TM], wh[TN], wl[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -187,6 +196,49 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void conv_x3_kernel(ConvX3Arg
 
     // ---- epilogue, staged through LDS (conv_x3_common.h): each wave parks its tile in its own slice of the idle staging buffer ----
     __syncthreads();  // all waves are done with the operand stages
+    if (p.splitk > 1) {
+        // ---- split-K combine (cdna_hip_programming.md section 5, "In-launch split-K reduction"): plain 16-byte slab stores in
+        // fragment order (1 KiB per wave instruction) -> every wave drains -> barrier -> one lane: agent release, drain, ticket ----
+        constexpr int FR = TN * TM;                       // f32x4 fragments per lane
+        constexpr int TILE_F = 4 * FR * 256;              // floats of one partial tile (4 waves x FR x 64 lanes x 4)
+        float* const tile_slab = p.slab + (size_t)bid * p.splitk * TILE_F;
+        float* const mine = tile_slab + (size_t)slice * TILE_F + (wave * FR) * 256 + lane * 4;
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int m = 0; m < TM; ++m) *(f32x4*)(mine + (n * TM + m) * 256) = acc[n][m];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* const flag = (unsigned*)smem;           // the staging buffers are idle: word 0 carries the ticket to all waves
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (always, and AFTER the fence: guideline 16 pitfall 12)
+            *flag = __hip_atomic_fetch_add(p.counters + bid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        const unsigned ticket = *flag;
+        if (ticket != (unsigned)(p.splitk - 1)) return;   // not the last arriver of this tile
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(p.counters + bid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+        }
+        __syncthreads();
+        // partial tiles added in SLICE order (this workgroup's own one re-read like the others): the same bits whoever came last
+        const float* src = tile_slab + (wave * FR) * 256 + lane * 4;
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int m = 0; m < TM; ++m) acc[n][m] = *(const f32x4*)(src + (n * TM + m) * 256);
+        for (int sl = 1; sl < p.splitk; ++sl) {
+            src += TILE_F;
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int m = 0; m < TM; ++m) acc[n][m] += *(const f32x4*)(src + (n * TM + m) * 256);
+        }
+        __syncthreads();  // `flag` (smem word 0) has been read by every wave before the epilogue re-uses the buffer
+    }
     conv_x3_epilogue<TM, TN>(p, acc, smem + wave * (TM * 16 * TN * 64), m0 + wm * (TM * 16), n0 + wn * (TN * 16), lane, grp);
 }
 
@@ -200,10 +252,35 @@ extern "C" int ufm_debug_set_conv_variant(int v) {
     return UFM_OK;
 }
 
+// Split-K factor of a layer: a function of its GEOMETRY ONLY (K-tiles and output pixels per image), never of the batch or the
+// group count, so that every pixel is summed in the same order whatever batch it is computed in.  Small maps with long K loops
+// (the 19^2 / 37^2 layers of the DPT heads: 72-216 K-tiles on grids of 6-172 tiles) are latency-bound chains of K-steps; cutting
+// the chain 2-6 ways multiplies the workgroups that share a CU.
+constexpr long long SPLITK_COUNTER_BYTES = 64 * 1024;  // 16384 tile counters in front of the slabs
+static int conv_x3_splitk_factor(int Ho, int Wo, int Cin, int KH, int KW, int passes) {
+    const int nk = KH * KW * (Cin / BK);
+    if (passes != 3 || (long long)Ho * Wo > 1600 || nk < 48) return 1;
+    const int s = nk / 24;
+    return s < 1 ? 1 : s > 6 ? 6 : s;
+}
+// rows = output pixels of ALL groups; bytes of counters + partial tiles for any tile shape the launcher may pick
+static long long conv_x3_splitk_bytes(long long rows, int Cout, int S) {
+    if (S <= 1) return 0;
+    const long long rpad = (rows + 127) / 128 * 128 + 128LL * 64, cpad = (Cout + 127) / 128 * 128;  // (+ one ragged tile per group, <= 64 groups)
+    return SPLITK_COUNTER_BYTES + rpad * cpad * 4 * S;
+}
+extern "C" long long ufm_conv_x3_splitk_ws_bytes(int groups, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    if (groups < 1 || B < 1 || KH < 1 || KW < 1 || stride < 1 || Cin % BK) return 0;
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return 0;
+    return conv_x3_splitk_bytes((long long)groups * B * Ho * Wo, Cout, conv_x3_splitk_factor(Ho, Wo, Cin, KH, KW, 3));
+}
+
 // Kernel choice for one problem (shared by the convolution and the Linear entry points).
 static void launch_conv_x3(const ConvX3Args& p, int passes, hipStream_t stream) {
     const int Cout = p.Cout, KH = p.KH, KW = p.KW, Cin = p.Cin;
     const long long M = p.M;
+    const int S = p.splitk;
     // Kernel choice.  Cout % 256 == 0 and a grid that fills the chip: the 256x256 8-phase kernel on the leading pixels
     // that make whole rounds of 256 CUs, the 128-row kernel on the rest (g_conv_variant: 0 auto, 1 = 128-row kernels
     // only, 2 = 8-phase on everything it accepts -- tests/tools).
@@ -211,7 +288,7 @@ static void launch_conv_x3(const ConvX3Args& p, int passes, hipStream_t stream) 
     auto launch128 = [&](const ConvX3Args& q) {
         const long long Mq = q.M - q.m_begin;
         const int ntm = (int)((Mq + 127) / 128) * G;  // row tiles of all groups (128-row kernels; the 64-row grids below scale the same way)
-        const long long blocks128 = (long long)ntm * (Cout % 128 == 0 ? Cout / 128 : Cout % 64 == 0 ? Cout / 64 : Cout / 32);
+        const long long blocks128 = (long long)ntm * (Cout % 128 == 0 ? Cout / 128 : Cout % 64 == 0 ? Cout / 64 : Cout / 32) * S;
         // small grid: 64x64 tiles, several co-resident blocks per CU.  Threshold from an end-to-end sweep (400 / 200 / 100:
         // 189.6 / 196.6 / 197.2 pairs/s with two micro-batches): at 128..400 blocks the 128-row tiles win
         if (passes == 1) {  // plain bf16: the two-stage kernels only
@@ -226,26 +303,26 @@ static void launch_conv_x3(const ConvX3Args& p, int passes, hipStream_t stream) 
             return;
         }
         if (Cout % 64 == 0 && blocks128 < 128) {
-            const unsigned grid = (unsigned)(((Mq + 63) / 64) * G * (Cout / 64));
+            const unsigned grid = (unsigned)(((Mq + 63) / 64) * G * (Cout / 64)) * S;
             // measured per layer (tools/conv_breakdown.py): the deep ring pays on long K loops only (19^2 768->256: 138 -> 102 us;
             // short loops lose 2-3 us to its prologue), and not at all on the 128x128 tile (37^2 RCU: 68 -> 83 us)
-            if (grid <= 512 && KH * KW * (Cin / 32) >= 64 && g_conv_variant != 3)
+            if (grid <= 512 && KH * KW * (Cin / 32) / S >= 64 && g_conv_variant != 3)
                 hipLaunchKernelGGL((conv_x3_kernel<64, 64, 4>), dim3(grid), dim3(256), 0, stream, q);
             else
                 hipLaunchKernelGGL((conv_x3_kernel<64, 64, 2>), dim3(grid), dim3(256), 0, stream, q);
         } else if (Cout % 128 == 0) {
-            hipLaunchKernelGGL((conv_x3_kernel<128, 128, 2>), dim3(ntm * (Cout / 128)), dim3(256), 0, stream, q);
+            hipLaunchKernelGGL((conv_x3_kernel<128, 128, 2>), dim3(ntm * (Cout / 128) * S), dim3(256), 0, stream, q);
         } else if (Cout % 64 == 0) {
-            hipLaunchKernelGGL((conv_x3_kernel<128, 64, 2>), dim3(ntm * (Cout / 64)), dim3(256), 0, stream, q);
+            hipLaunchKernelGGL((conv_x3_kernel<128, 64, 2>), dim3(ntm * (Cout / 64) * S), dim3(256), 0, stream, q);
         } else {
-            hipLaunchKernelGGL((conv_x3_kernel<128, 32, 2>), dim3(ntm * (Cout / 32)), dim3(256), 0, stream, q);
+            hipLaunchKernelGGL((conv_x3_kernel<128, 32, 2>), dim3(ntm * (Cout / 32) * S), dim3(256), 0, stream, q);
         }
     };
     // 8-phase tile: 256 px x 256 cout (Cout % 256 == 0)
     const int tile_n = 256, tile_m = 256;
     const bool ok8 = Cout % 256 == 0 && KH * KW * (Cin / 32) >= 2 && p.in_plane < (1ll << 31) && p.w_plane < (1ll << 31);
     const long long t8 = ((M + tile_m - 1) / tile_m) * (Cout / tile_n) * G;  // 8-phase tiles of all groups
-    if (passes == 1) {
+    if (passes == 1 || S > 1) {  // (split-K lives in the 128- / 64-row kernels: its layers are the small maps the 8-phase tile never fits)
         launch128(p);
     } else if (ok8 && g_conv_variant == 2) {
         ufm_launch_conv_x3_8ph(p, stream);
@@ -276,14 +353,15 @@ extern "C" int ufm_conv2d_nhwc_bf16x3(const uint16_t* in, int B, int H, int W, i
                                       const uint16_t* res1, const uint16_t* res2, int shuffle, uint16_t* out,
                                       uint16_t* out_relu, const uint16_t* zero_page, int passes, void* stream) {
     return ufm_conv2d_nhwc_bf16x3_grouped(in, 1, 0, B, H, W, Cin, weight, Cout, KH, KW, stride, pad, relu_in, bias, act, res1, res2, shuffle, out, out_relu,
-                                          zero_page, passes, stream);
+                                          zero_page, passes, nullptr, 0, stream);
 }
 
 // `groups` convolutions of identical geometry in one launch (conv_x3_common.h ConvX3Args): the two DPT heads.
 extern "C" int ufm_conv2d_nhwc_bf16x3_grouped(const uint16_t* in, int groups, int in_shared, int B, int H, int W, int Cin, const uint16_t* weight,
                                               int Cout, int KH, int KW, int stride, int pad, int relu_in, const float* bias, int act,
                                               const uint16_t* res1, const uint16_t* res2, int shuffle, uint16_t* out,
-                                              uint16_t* out_relu, const uint16_t* zero_page, int passes, void* stream) {
+                                              uint16_t* out_relu, const uint16_t* zero_page, int passes, void* splitk_ws, long long splitk_ws_bytes,
+                                              void* stream) {
     UFM_REQUIRE(in && weight && out && zero_page, "ufm_conv2d_nhwc_bf16x3: null pointer");
     UFM_REQUIRE(groups >= 1 && groups <= 64, "ufm_conv2d_nhwc_bf16x3: groups=%d out of range", groups);
     UFM_REQUIRE(passes == 3 || passes == 1, "ufm_conv2d_nhwc_bf16x3: passes=%d must be 3 (bf16x3) or 1 (plain bf16)", passes);
@@ -312,6 +390,18 @@ extern "C" int ufm_conv2d_nhwc_bf16x3_grouped(const uint16_t* in, int groups, in
     p.groups = groups, p.Mg = (int)M;
     p.in_group = in_shared ? 0 : (long long)B * H * W * Cin;
     p.w_group = (long long)Cout * KH * KW * Cin;
+    p.splitk = 1;
+    if (splitk_ws && !shuffle) {  // a workspace is offered: split the K loop of the layers conv_x3_splitk_factor names
+        const int S = conv_x3_splitk_factor(Ho, Wo, Cin, KH, KW, passes);
+        if (S > 1) {
+            const long long need = conv_x3_splitk_bytes(M * groups, Cout, S);
+            UFM_REQUIRE(((uintptr_t)splitk_ws % 16) == 0 && splitk_ws_bytes >= need, "ufm_conv2d_nhwc_bf16x3: split-K workspace of %lld bytes, this layer needs %lld (ufm_conv_x3_splitk_ws_bytes)", splitk_ws_bytes, need);
+            UFM_REQUIRE(((M + 63) / 64 + groups) * (long long)((Cout + 63) / 64) <= SPLITK_COUNTER_BYTES / 4, "ufm_conv2d_nhwc_bf16x3: too many tiles for the split-K counters");
+            p.splitk = S;
+            p.counters = (unsigned*)splitk_ws;
+            p.slab = (float*)((char*)splitk_ws + SPLITK_COUNTER_BYTES);
+        }
+    }
     launch_conv_x3(p, passes, (hipStream_t)stream);
     UFM_CHECK_LAUNCH("ufm_conv2d_nhwc_bf16x3");
     return UFM_OK;
@@ -337,7 +427,7 @@ extern "C" int ufm_gemm_bf16x3(const uint16_t* A, const uint16_t* W, int M, int 
     p.gamma = gamma;
     p.res_f32 = res;
     p.out_f32 = out_dtype == UFM_F32 ? (float*)out : nullptr;
-    p.groups = 1, p.Mg = M;
+    p.groups = 1, p.Mg = M, p.splitk = 1;
     launch_conv_x3(p, 3, (hipStream_t)stream);
     UFM_CHECK_LAUNCH("ufm_gemm_bf16x3");
     return UFM_OK;

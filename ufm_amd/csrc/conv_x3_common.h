@@ -27,6 +27,13 @@ struct ConvX3Args {
     // stay PER GROUP (rows [m_begin, M) of every group are covered by the launch).  groups = 1: Mg = rows of the one problem.
     int groups, Mg;
     long long in_group, w_group;
+    // Deterministic split-K (conv_bf16x3.hip, the 128- / 64-row kernels): the K loop of a tile is cut into `splitk` consecutive
+    // ranges of K-tiles, one workgroup each; every workgroup parks its fp32 partial tile in `slab`, the LAST one to arrive (an
+    // agent-scope arrival counter per tile) adds the partials IN SLICE ORDER and runs the epilogue.  splitk depends on the layer's
+    // geometry only (never on the batch), so a pixel's result is the same bits at any batch size.  splitk = 1: off.
+    int splitk;
+    float* slab;          // [tiles][splitk][BM * BN] partial tiles (fragment order)
+    unsigned* counters;   // [tiles], zero between launches (the last arriver resets its tile's word)
 };
 
 // tile row index over all groups -> (group, tile row inside the group); tiles_pg = row tiles per group of this launch

@@ -283,6 +283,7 @@ class Engine:
         # values still from both views) -- the reference decodes view 1 only (ufm.py:637-641) and nothing else reads that block's
         # view-2 rows (UFM-Refine's classification head does: off there).  Exact: bit-identical to the full block on the kept rows.
         self.last_layer_view1 = True
+        self.mb_bounds = None  # lab: explicit micro-batch boundaries, e.g. [0, 5, 8]
         self.micro_batches = 2  # >1: the batch is split into micro-batches that run concurrently on separate HIP streams
         # joint_heads: the micro-batch streams run the TRUNK only (patchify .. info sharing: GEMM / attention launches whose
         # partial rounds and HBM-bound epilogues overlap across streams); their view-1 feature pyramids land in one
@@ -303,6 +304,12 @@ class Engine:
         # 9.11-9.14 vs 9.01-9.15 ms graph replay at B = 1 -- the two streams already interleave one head's small-grid layers with
         # the other's large ones, which one serial chain of doubled grids does not
         self.group_heads = False
+        # conv_splitk: deterministic split-K for the DPT heads' small-map long-K layers (19^2 / 37^2: latency-bound chains of 72-216
+        # K-steps on grids of a few dozen tiles); the factor depends on the layer geometry only, so results stay batch-invariant.
+        # OFF by default: same-box A/B (round 4, profiles/r04/conv_splitk_ab.log) one-pair graph replay 8.75-8.88 vs 8.86-8.96 ms
+        # (-1 %), B = 8 217.7 vs 218.6 pairs/s (+0.4 % slower) -- the two head streams already hide those chains behind each
+        # other -- and it changes the last bits of the heads' sums (9e-5 px); not worth a second set of results
+        self.conv_splitk = False
         self.fused_tail = True  # ufm_dpt_tail_fused where the head has the UFM-Base tail shape (bit-identical to the unfused path)
         # DPT heads on separate HIP streams: None = automatic (yes for a single-stream forward -- one pair: 9.84 -> 8.97 ms
         # graph replay, the small-grid layers of one head fill the other's tails -- no inside a micro-batch worker, where the
@@ -510,15 +517,31 @@ class Engine:
             assert res_row_mod == 0 and out_row_group == 0 and out.dtype == torch.float32
             hip.conv2d(x, 1, 1, M, lin.k, lin.w, lin.n, 1, 1, 1, 0, out, self.zero, bias=lin.b, act=act, gamma=gamma, res1=res)
 
-    def conv(self, x, B, H, W, c: _Conv, out, *, relu_in=False, act=hip.ACT_NONE, res1=None, res2=None, out_relu=None, replicate=False, in_shared=False):
+    def conv(self, x, B, H, W, c: _Conv, out, *, relu_in=False, act=hip.ACT_NONE, res1=None, res2=None, out_relu=None, replicate=False, in_shared=False, ws: Optional[str] = None):
         """``c`` a _ConvG: the grouped launch (B = images per group; x / out / res hold groups * B images, group-major; ``in_shared``:
-        x holds B images that every group reads)."""
+        x holds B images that every group reads).  ``ws``: name of the caller's split-K workspace (one per concurrent launch
+        sequence): the small-map long-K layers then run the deterministic split-K form of ufm_conv2d_nhwc_bf16x3_grouped."""
         if c.w.dtype == torch.bfloat16:
+            groups = getattr(c, "groups", 1)
+            wsbuf = None
+            if ws is not None and self.conv_splitk and not c.shuffle and getattr(c, "passes", 3) == 3:
+                need = hip.lib().ufm_conv_x3_splitk_ws_bytes(groups, B, H, W, c.cin, c.cout, c.k, c.k, c.stride, c.pad)
+                if need > 0:
+                    wsbuf = self._splitk_ws(ws, need)
             hip.conv2d_x3(x, B, H, W, c.cin, c.w, c.cout, c.k, c.k, c.stride, c.pad, out, self.zero, relu_in=relu_in, bias=c.b, act=act, res1=res1, res2=res2, shuffle=c.shuffle, out_relu=out_relu,
-                          passes=getattr(c, "passes", 3), replicate=replicate, groups=getattr(c, "groups", 1), in_shared=in_shared)
+                          passes=getattr(c, "passes", 3), replicate=replicate, groups=groups, in_shared=in_shared, splitk_ws=wsbuf)
         else:
             assert out_relu is None
             hip.conv2d(x, B, H, W, c.cin, c.w, c.cout, c.k, c.k, c.stride, c.pad, out, self.zero, relu_in=relu_in, bias=c.b, act=act, res1=res1, res2=res2, shuffle=c.shuffle, replicate=replicate)
+
+    def _splitk_ws(self, name: str, nbytes: int) -> torch.Tensor:
+        """Zero-filled split-K workspace ``name`` (grown to the largest layer that asked; the kernels leave its counters zero)."""
+        name = getattr(self._tls, "ns", "") + name + "_splitk_ws"
+        t = self._bufs.get(name)
+        if t is None or t.numel() * 4 < nbytes:
+            t = torch.zeros((nbytes + 3) // 4, device=self.dev, dtype=torch.float32)
+            self._bufs[name] = t
+        return t
 
     def hbuf(self, name: str, shape: Tuple[int, ...]) -> torch.Tensor:
         """Head activation buffer: fp32 [shape] or the split format (2, *shape) bf16."""
@@ -689,16 +712,16 @@ class Engine:
         for i in range(4):
             lvl = levels[hw.hooks[i]]
             t = self.hbuf(f"{tag}_act{i}", (Bt, gh, gw, ld[i]))
-            self.conv(lvl, B, gh, gw, hw.act[i][0], t, in_shared=G > 1)  # every head reads the same pyramid level
+            self.conv(lvl, B, gh, gw, hw.act[i][0], t, in_shared=G > 1, ws=tag)  # every head reads the same pyramid level
             u = t
             if i < 2 or i == 3:
                 u = self.hbuf(f"{tag}_post{i}", (Bt, sizes[i][0], sizes[i][1], ld[i]))
-                self.conv(t, B, gh, gw, hw.act[i][1], u)
+                self.conv(t, B, gh, gw, hw.act[i][1], u, ws=tag)
             ri = self.hbuf(f"{tag}_rn{i}", (Bt, sizes[i][0], sizes[i][1], Fd))
             # split mode: the producer of an RCU input also writes relu(x) (ufm_conv2d_nhwc_bf16x3 out_relu), which takes
             # the ReLU out of the consumer's MFMA loop; the fp32 kernels apply it on their fragments (relu_in)
             rr = self.hbuf(f"{tag}_rn{i}_relu", (Bt, sizes[i][0], sizes[i][1], Fd)) if self.head_split else None
-            self.conv(u, B, sizes[i][0], sizes[i][1], hw.rn[i], ri, out_relu=rr)
+            self.conv(u, B, sizes[i][0], sizes[i][1], hw.rn[i], ri, out_relu=rr, ws=tag)
             r.append((ri, rr))
 
         def rcu(xs, pair, h, w, name, extra_res=None, want_relu=False):
@@ -708,11 +731,11 @@ class Engine:
             o = self.hbuf(f"{tag}_{name}_o", (Bt, h, w, Fd))
             orl = self.hbuf(f"{tag}_{name}_or", (Bt, h, w, Fd)) if (want_relu and self.head_split) else None
             if self.head_split:
-                self.conv(xr, B, h, w, pair[0], t1, act=hip.ACT_RELU)  # relu applied once, by the producers
-                self.conv(t1, B, h, w, pair[1], o, res1=x, res2=extra_res, out_relu=orl)
+                self.conv(xr, B, h, w, pair[0], t1, act=hip.ACT_RELU, ws=tag)  # relu applied once, by the producers
+                self.conv(t1, B, h, w, pair[1], o, res1=x, res2=extra_res, out_relu=orl, ws=tag)
             else:
-                self.conv(x, B, h, w, pair[0], t1, relu_in=True)
-                self.conv(t1, B, h, w, pair[1], o, relu_in=True, res1=x, res2=extra_res)
+                self.conv(x, B, h, w, pair[0], t1, relu_in=True, ws=tag)
+                self.conv(t1, B, h, w, pair[1], o, relu_in=True, res1=x, res2=extra_res, ws=tag)
             return (o, orl)
 
         path = None
@@ -726,7 +749,7 @@ class Engine:
             o, _ = rcu(s, f["r2"], h, w, f"f{lvl}b")
             # out_conv (1x1) commutes with the bilinear x2 (weights sum to 1): run it at low resolution
             c = self.hbuf(f"{tag}_f{lvl}c", (Bt, h, w, Fd))
-            self.conv(o, B, h, w, f["out"], c)
+            self.conv(o, B, h, w, f["out"], c, ws=tag)
             if lvl == 3:
                 th, tw = sizes[2]  # refinenet4 output is cropped to layer-3's grid
                 path = self.hbuf(f"{tag}_p{lvl}", (Bt, th, tw, Fd))
@@ -736,7 +759,7 @@ class Engine:
                 hip.upsample_bilinear(c, Bt, h, w, Fd, path, 2 * h, 2 * w)
         h8, w8 = 2 * sizes[0][0], 2 * sizes[0][1]
         c1 = self.hbuf(f"{tag}_pc1", (Bt, h8, w8, hw.p_conv1.cout))
-        self.conv(path, B, h8, w8, hw.p_conv1, c1)
+        self.conv(path, B, h8, w8, hw.p_conv1, c1, ws=tag)
         if G > 1:  # each head's own tail on its B images of the stacked p_conv1 output (callers checked _tail_fusable for every head)
             plane = Bt * h8 * w8 * hw.p_conv1.cout
             results = []
@@ -757,7 +780,7 @@ class Engine:
             up = self.hbuf(f"{tag}_up", (B, H, W, hw.p_conv1.cout))
             hip.upsample_bilinear(c1, B, h8, w8, hw.p_conv1.cout, up, H, W)
             c2 = self.hbuf(f"{tag}_pc2", (B, H, W, c2a.cout))
-            self.conv(up, B, H, W, c2a, c2, act=hip.ACT_RELU)
+            self.conv(up, B, H, W, c2a, c2, act=hip.ACT_RELU, ws=tag)
             hip.head_tail(c2, B * H * W, H * W, hw.tail_cin, hw.tail_w, hw.tail_b, hw.tail_cout, hw.kinds, hw.scale, hw.shift, out, logits)
         return self._adaptor_outputs(hw, out, logits, B, H, W)
 
@@ -908,6 +931,8 @@ class Engine:
             self._tls.ns = ""
             return self._forward_images(src, tgt, layout, scale3, shift3, H, W, Hs, Ws, Ht, Wt, symmetrized)
         bounds = [(i * B) // nmb for i in range(nmb + 1)]
+        if self.mb_bounds is not None and self.mb_bounds[-1] == B:  # lab: explicit micro-batch boundaries (tools/lab/mb_split.py)
+            bounds, nmb = list(self.mb_bounds), len(self.mb_bounds) - 1
         gh, gw = H // self.P, W // self.P
         self._pos_tables(H, W)  # shared read-only tables are built here, before the workers start
         if self.info_cross:

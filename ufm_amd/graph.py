@@ -38,7 +38,7 @@ class GraphedPredictor:
         eng = self._engine = Engine(model, model.numerics)  # private workspace + packed weights: nothing else ever runs on it
         if shared is not None:
             eng.concurrent_heads, eng.fused_tail = shared.concurrent_heads, shared.fused_tail
-            eng.group_heads, eng.last_layer_view1 = shared.group_heads, shared.last_layer_view1
+            eng.group_heads, eng.last_layer_view1, eng.conv_splitk = shared.group_heads, shared.last_layer_view1, shared.conv_splitk
         eng.micro_batches = 1  # one stream, one host thread: the capture records a single linear launch sequence
         model._engine = eng
         try:

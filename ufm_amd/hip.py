@@ -56,7 +56,7 @@ SIGNATURES = {
     "ufm_debug_attention_stamps": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "ufm_conv2d_nhwc_f32": [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp],
     "ufm_conv2d_nhwc_bf16x3": [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp],
-    "ufm_conv2d_nhwc_bf16x3_grouped": [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp],
+    "ufm_conv2d_nhwc_bf16x3_grouped": [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, C.c_longlong, _vp],
     "ufm_gemm_bf16x3": [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "ufm_attention_bf16x3": [_vp, _vp, _i, _i, _i, _f, _vp],
     "ufm_upsample_bilinear_nhwc": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp],
@@ -77,7 +77,7 @@ SIGNATURES = {
     "ufm_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
     "ufm_add_f32": [_vp, _vp, _vp, _i64, _vp],
 }
-PLAIN = {"ufm_group_norm_ws_floats": (C.c_int, [C.c_int, C.c_int, C.c_int]), "ufm_abi_version": (C.c_int, []), "ufm_last_error": (C.c_char_p, []), "ufm_built_arch": (C.c_char_p, [])}
+PLAIN = {"ufm_conv_x3_splitk_ws_bytes": (C.c_longlong, [C.c_int] * 10), "ufm_group_norm_ws_floats": (C.c_int, [C.c_int, C.c_int, C.c_int]), "ufm_abi_version": (C.c_int, []), "ufm_last_error": (C.c_char_p, []), "ufm_built_arch": (C.c_char_p, [])}
 
 
 def lib() -> C.CDLL:
@@ -301,16 +301,16 @@ def conv2d(x, B, H, W, Cin, weight, Cout, KH, KW, stride, pad, out, zero_page, *
 
 
 def conv2d_x3(x, B, H, W, Cin, weight, Cout, KH, KW, stride, pad, out, zero_page, *, relu_in=False, bias=None, act=ACT_NONE, res1=None, res2=None, shuffle=0, out_relu=None, passes=3, replicate=False,
-              groups=1, in_shared=False):
+              groups=1, in_shared=False, splitk_ws=None):
     """bf16x3 split-precision conv; x / weight / res / out are (2, ...) bf16 tensors (UFM_BF16X2).
     passes=1: the hi planes only (a plain bf16 convolution with fp32 accumulation), same operand and output format.
     groups > 1: that many convolutions of identical geometry in one launch (ufm_conv2d_nhwc_bf16x3_grouped); B is per group."""
     Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
-    if groups > 1:
-        _t("ufm_conv2d_nhwc_bf16x3", (2.0 * groups * B * Ho * Wo * Cout * KH * KW * Cin, f"G{groups} B{B} {H}x{W} {Cin}->{Cout} k{KH}" + (f" s{stride}" if stride != 1 else "") + (f" shuffle{shuffle}" if shuffle else "")))
+    if groups > 1 or splitk_ws is not None:
+        _t("ufm_conv2d_nhwc_bf16x3", (2.0 * groups * B * Ho * Wo * Cout * KH * KW * Cin, (f"G{groups} " if groups > 1 else "") + f"B{B} {H}x{W} {Cin}->{Cout} k{KH}" + (f" s{stride}" if stride != 1 else "") + (f" shuffle{shuffle}" if shuffle else "")))
         _check(
             lib().ufm_conv2d_nhwc_bf16x3_grouped(_p(x), groups, int(in_shared), B, H, W, Cin, _p(weight), Cout, KH, KW, stride, pad, int(relu_in) | (2 if replicate else 0), _p(bias), act, _p(res1), _p(res2),
-                                                 shuffle, _p(out), _p(out_relu), _p(zero_page), passes, _stream()),
+                                                 shuffle, _p(out), _p(out_relu), _p(zero_page), passes, _p(splitk_ws), splitk_ws.numel() * splitk_ws.element_size() if splitk_ws is not None else 0, _stream()),
             "ufm_conv2d_nhwc_bf16x3",  # (the timer's family name; the entry point is ufm_conv2d_nhwc_bf16x3_grouped)
         )
         return
