@@ -22,7 +22,7 @@ def poll(stop, out):
         time.sleep(0.2)
 
 
-def under_load(name, fn, seconds=3.0):
+def under_load(name, fn, seconds=3.0, per_sync=20):
     stop, samples = threading.Event(), []
     th = threading.Thread(target=poll, args=(stop, samples))
     for _ in range(5):
@@ -31,10 +31,10 @@ def under_load(name, fn, seconds=3.0):
     th.start()
     t0, n = time.perf_counter(), 0
     while time.perf_counter() - t0 < seconds:
-        for _ in range(20):
+        for _ in range(per_sync):
             fn()
         torch.cuda.synchronize()
-        n += 20
+        n += per_sync
     dt = time.perf_counter() - t0
     stop.set(); th.join()
     s = [x for x in samples[2:] if x[0]]
@@ -70,3 +70,17 @@ xl = torch.randn(M, 1024, device=DEV)
 g1, b1 = torch.ones(1024, device=DEV), torch.zeros(1024, device=DEV)
 ol = torch.empty(M, 1024, device=DEV, dtype=torch.bfloat16)
 under_load("layernorm 21920 x 1024 -> bf16", lambda: hip.layernorm(xl, 1024, None, M, 1024, g1, b1, 1e-6, ol))
+
+# the benchmark step itself (UFM-Base, 8 pairs, two micro-batch streams): what share of the power cap does a whole step draw?
+import ufm_amd  # noqa: E402
+from ufm_amd.modules import init_weights_  # noqa: E402
+
+model = ufm_amd.UniFlowMatchConfidence(**ufm_amd.ufm_base_config()).eval()
+init_weights_(model, 0)
+model = model.to(DEV)
+g = torch.Generator().manual_seed(1)
+src = torch.randint(0, 256, (8, 518, 518, 3), dtype=torch.uint8, generator=g).to(DEV)
+tgt = torch.randint(0, 256, (8, 518, 518, 3), dtype=torch.uint8, generator=g).to(DEV)
+under_load("bench step: UFM-Base B=8 518^2 fast (2 streams)", lambda: model.predict_correspondences_batched(src, tgt), 4.0, 4)
+model.engine().micro_batches = 1
+under_load("bench step, one stream", lambda: model.predict_correspondences_batched(src, tgt), 4.0, 4)
