@@ -307,6 +307,44 @@ def test_ufm_base_full_size_parity(env):
     assert e_fast_ac.mean().item() <= 1.5 * e_ac.mean().item() and e_fast_ac.max().item() <= 1.5 * e_ac.max().item()
 
 
+def test_second_weight_regime_outlier_channels_and_small_layerscale(env):
+    """The fast-mode bound above rests on ONE weight statistic (random O(1) weights, LayerScale 1 +- 0.1).  A second, harsher one
+    on a mid-size model (256-wide, 6 + 4 blocks, 154 x 154 px): LayerScale gammas of mixed sign and magnitude ~0.3 and four "massive activation" channels in the position embedding (x 25: the outlier channels trained ViTs carry
+    through their residual stream, which is what makes bf16 rounding of the LayerNorm input hurt).  parity / precise stay inside the
+    1e-3 px gate; "fast" stays within 1.5x of the distance the reference's own bf16-autocast policy (base.py:273) moves the oracle."""
+    ufm_amd, R = env
+    kw = dict(enc_dim=256, enc_depth=6, enc_heads=4, info_dim=256, info_depth=4, info_heads=4, layer_dims=(32, 64, 128, 256), feature_dim=64,
+              resolution_wh=(154, 154), native_img_size=154)
+    oracle = R.UFMRef(**R.make_config(**kw)).eval()
+    R.init_weights_(oracle, 5)
+    g = torch.Generator().manual_seed(17)
+    with torch.no_grad():
+        for name, prm in oracle.named_parameters():
+            if name.endswith("gamma"):
+                prm.copy_(0.3 * torch.randn(prm.shape, generator=g))
+            elif "pos_embed" in name:
+                prm[..., :4] *= 25.0
+    prod = ufm_amd.UniFlowMatchConfidence(**ufm_amd.configs.make_config(**kw)).eval()
+    prod.load_state_dict(oracle.state_dict(), strict=True)
+    prod = prod.to(DEV)
+    src, tgt = u8((2, 154, 154, 3), 91), u8((2, 154, 154, 3), 92)
+    o = oracle.predict_correspondences_batched(src, tgt)
+    mx = o.flow.flow_output.abs().max().item()
+    for mode in ("parity", "precise"):
+        p = prod.set_numerics(mode).predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
+        df, dm, _ = compare(o, p)
+        print(f"second weight regime, {mode}: flow max-abs {df:.3g} px (range {mx:.3g}), mask {dm:.3g}")
+        assert df <= 1e-3 * max(1.0, mx) and dm <= 1e-3, (mode, df, dm, mx)
+    pf = prod.set_numerics("fast").predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
+    oracle.autocast_bf16 = True
+    oa = oracle.predict_correspondences_batched(src, tgt)
+    oracle.autocast_bf16 = False
+    e_ac = (oa.flow.flow_output - o.flow.flow_output).abs()
+    e_fast = (pf.flow.flow_output.cpu() - o.flow.flow_output).abs()
+    print(f"second weight regime: autocast-oracle vs fp32 oracle max {e_ac.max():.3g} mean {e_ac.mean():.3g}; fast vs fp32 oracle max {e_fast.max():.3g} mean {e_fast.mean():.3g} (range {mx:.3g})")
+    assert e_fast.mean().item() <= 1.5 * e_ac.mean().item() and e_fast.max().item() <= 1.5 * e_ac.max().item(), (e_fast.mean().item(), e_fast.max().item(), e_ac.mean().item(), e_ac.max().item())
+
+
 def test_config4_ufm_refine_full_size_parity(env):
     """BASELINE config 4: UFM-Refine (UniFlowMatchClassificationRefinement) 518x518, B=1: the whole path incl.
     the patch-MLP feature head and the fused bicubic-gather/softmax refinement vs the fp32 CPU oracle."""
