@@ -87,24 +87,44 @@ __global__ __launch_bounds__(256, KS == 1 ? 2 : 1) void gemm_bf16_kernel(GemmArg
 #pragma unroll
         for (int j = 0; j < KS; ++j)
             if (kt + KS + j < nk) stage(buf_of(kt + KS + j), kt + KS + j);
-#pragma unroll
-        for (int j = 0; j < KS; ++j) {
-            if (KS > 1 && kt + j >= nk) break;
+        auto load_frags = [&](bf16x8 (&a)[4], bf16x8 (&b)[4], int j, int kk) {
             const char* s = smem + buf_of(kt + j) * STAGE_BYTES;
+            const int coff = ((kk * 4 + fq) ^ sw) * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = *(const bf16x8*)(s + a_off[i] + coff);
+                b[i] = *(const bf16x8*)(s + b_off[i] + coff);
+            }
+        };
+        auto mma16 = [&](const bf16x8 (&a)[4], const bf16x8 (&b)[4]) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[n], a[m], acc[n][m], 0, 0, 0);
+        };
+        if constexpr (KS == 2) {
+            // The lone block (at most one per CU: nothing else covers its LDS latency) reads the fragments of k-substep s + 1 while
+            // the 16 MFMAs of substep s issue: two register sets, 512 registers per wave at one block per CU.  The MFMA sequence of
+            // every accumulator is unchanged (k order 0, 1, 2, ...): bit-identical to KS = 1.
+            bf16x8 a0[4], b0[4], a1[4], b1[4];
+            const bool two = kt + 1 < nk;
+            load_frags(a0, b0, 0, 0);
+            load_frags(a1, b1, 0, 1);
+            mma16(a0, b0);
+            if (two) load_frags(a0, b0, 1, 0);
+            mma16(a1, b1);
+            if (two) {
+                load_frags(a1, b1, 1, 1);
+                mma16(a0, b0);
+                mma16(a1, b1);
+            }
+        } else {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                const int coff = ((kk * 4 + fq) ^ sw) * 16;
                 bf16x8 a[4], b[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    a[i] = *(const bf16x8*)(s + a_off[i] + coff);
-                    b[i] = *(const bf16x8*)(s + b_off[i] + coff);
-                }
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-#pragma unroll
-                    for (int m = 0; m < 4; ++m)
-                        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[n], a[m], acc[n][m], 0, 0, 0);
+                load_frags(a, b, 0, kk);
+                mma16(a, b);
             }
         }
     }
