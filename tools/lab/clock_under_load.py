@@ -71,6 +71,20 @@ g1, b1 = torch.ones(1024, device=DEV), torch.zeros(1024, device=DEV)
 ol = torch.empty(M, 1024, device=DEV, dtype=torch.bfloat16)
 under_load("layernorm 21920 x 1024 -> bf16", lambda: hip.layernorm(xl, 1024, None, M, 1024, g1, b1, 1e-6, ol))
 
+# numerics "precise": the split-format trunk kernels
+def _split(x):
+    hi = x.to(torch.bfloat16)
+    return torch.stack([hi, (x - hi.float()).to(torch.bfloat16)], 0).contiguous()
+
+
+qkv3 = _split(torch.randn(16 * 1370, 3 * 1024, device=DEV))
+ao3 = torch.zeros(2, 16 * 1370, 1024, device=DEV, dtype=torch.bfloat16)
+under_load("attention bf16x3 B16 N1370 H16", lambda: hip.attention_x3(qkv3, ao3, 16, 1370, 16, 0.125))
+A3, W3 = _split(torch.randn(M, 1024, device=DEV)), _split(torch.randn(3072, 1024, device=DEV) * 0.03)
+o3 = torch.zeros(2, M, 3072, device=DEV, dtype=torch.bfloat16)
+under_load("gemm bf16x3 QKV M21920 N3072 K1024", lambda: hip.gemm_x3(A3, W3, M, 3072, 1024, o3, zero))
+del qkv3, ao3, A3, W3, o3
+
 # the benchmark step itself (UFM-Base, 8 pairs, two micro-batch streams): what share of the power cap does a whole step draw?
 import ufm_amd  # noqa: E402
 from ufm_amd.modules import init_weights_  # noqa: E402
