@@ -767,6 +767,32 @@ def test_hip_graph_survives_eager_calls_with_other_shapes_and_numerics(env):
         gp(a, b)
 
 
+def test_hip_graph_capture_with_level_chain_branches_inside_the_two_stream_heads(env):
+    """The round-3 capture crash, as a regression test.  Cause (bisected in round 4, tools/lab/capture_debug.py): a stream forked from
+    an ALREADY FORKED stream inside a hipGraph capture (the level chains of the covisibility head, forked from that head's side
+    stream) makes hipStreamEndCapture segfault on ROCm 7; forks that all start at the capture's origin stream -- with joins between
+    sibling streams -- capture and replay fine.  Engine.level_streams (off by default: it measured slower) runs the heads' four
+    level chains on side streams that fork from the stream the head's own stream was forked from: capture it inside the
+    two-stream heads and require the replay to equal the eager result bit for bit."""
+    ufm_amd, _ = env
+    _, prod = build_pair(env)
+    prod.set_numerics("fast")
+    eng = prod.engine()
+    a, b = u8((1, 56, 56, 3), 51).to(DEV), u8((1, 56, 56, 3), 52).to(DEV)
+    want = prod.predict_correspondences_batched(a, b).flow.flow_output.clone()
+    eng.level_streams, eng.level_streams_max_images = True, 4
+    try:
+        assert eng.concurrent_heads in (None, True)  # single-stream forward: the two heads run on two streams
+        got = prod.predict_correspondences_batched(a, b).flow.flow_output.clone()
+        assert torch.equal(got, want)
+        gp = ufm_amd.GraphedPredictor(prod, a, b)
+        assert len(gp._engine._level_streams) == 2 and all(len(v) == 3 for v in gp._engine._level_streams.values())  # both heads forked three branches
+        assert torch.equal(gp(a, b).flow.flow_output, want)
+        assert torch.equal(gp(b, a).flow.flow_output, prod.predict_correspondences_batched(b, a).flow.flow_output)
+    finally:
+        eng.level_streams, eng.level_streams_max_images = False, 2
+
+
 def test_bench_n_gt_1_branch_rehearsed_on_one_rank_over_rccl():
     """bench.py's own N > 1 path (ShardedPredictor + RCCL all_gather ring + the gathered-vs-recomputed check) run as a child
     process with UFM_BENCH_FORCE_DIST=1 (a one-rank group on backend nccl): the JSON line must carry the gather check."""

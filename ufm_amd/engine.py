@@ -316,6 +316,14 @@ class Engine:
         # other micro-batch already does that: 166 vs 168 pairs/s); True / False force it
         self.concurrent_heads: Optional[bool] = None
         self._head_streams: Dict[str, List[torch.cuda.Stream]] = {}
+        # level_streams: the DPT heads' four level chains on side streams (graph branches under capture) when at most
+        # `level_streams_max_images` images go through a head call.  OFF: slower at every batch size -- 8 pairs 37.8 vs 37.1 ms (round 3),
+        # one pair 9.8 vs 9.0 ms graph replay, two pairs 15.2 vs 14.2 (round 4, profiles/r04/capture_nested_fork.log): eight streams
+        # of latency-bound launches delay the critical fusion chain more than they shorten it.  Kept because it carries the fix of
+        # the round-3 capture crash (forks start at the capture's origin stream; see _head) and the test that guards it.
+        self.level_streams = False
+        self.level_streams_max_images = 2
+        self._level_streams: Dict[Any, List[torch.cuda.Stream]] = {}
 
     # ------------------------------------------------------------------ packing
     def _pack(self) -> None:
@@ -696,33 +704,58 @@ class Engine:
         return x, Np, N
 
     # ------------------------------------------------------------------ DPT head
-    def _head(self, hw, tag: str, levels: List[torch.Tensor], level_dims: List[int], B: int, gh: int, gw: int, H: int, W: int):
+    def _head(self, hw, tag: str, levels: List[torch.Tensor], level_dims: List[int], B: int, gh: int, gw: int, H: int, W: int, fork_from: Optional[torch.cuda.Stream] = None):
         """[U] DPTFeature + DPTRegressionProcessor + adaptors on NHWC maps.  ``hw``: one packed head (_Head) -> that head's
         adaptor outputs; or a _HeadG (several heads of identical layer shapes) -> every layer up to p_conv1 is ONE grouped launch
         on a head-major stacked batch of G * B images, then each head's own tail on its slice; returns a list of adaptor outputs
         in the order of ``hw.heads``.  Bit-identical either way (tests)."""
-        # (Measured in round 3 and not kept: the four level chains on four HIP streams -- 37.8 vs 37.1 ms per step at B = 8,
-        #  and a nested stream fork inside the two-stream head capture crashed hipGraph capture at B = 1.)
         G = getattr(hw, "groups", 1)
         Bt = G * B  # images in every activation buffer of this call
         Fd = hw.feature_dim
         ld = hw.layer_dims
         sizes = [(4 * gh, 4 * gw), (2 * gh, 2 * gw), (gh, gw), ((gh - 1) // 2 + 1, (gw - 1) // 2 + 1)]
-        r = []
-        for i in range(4):
+        def chain(i: int):
+            """Level i up to its layer_rn output: 1x1 projection, resize (ConvTranspose x4 / x2, identity, 3x3 stride 2), bias-free 3x3."""
+            wsn = f"{tag}_l{i}"  # (a split-K workspace per concurrently running chain)
             lvl = levels[hw.hooks[i]]
             t = self.hbuf(f"{tag}_act{i}", (Bt, gh, gw, ld[i]))
-            self.conv(lvl, B, gh, gw, hw.act[i][0], t, in_shared=G > 1, ws=tag)  # every head reads the same pyramid level
+            self.conv(lvl, B, gh, gw, hw.act[i][0], t, in_shared=G > 1, ws=wsn)  # every head reads the same pyramid level
             u = t
             if i < 2 or i == 3:
                 u = self.hbuf(f"{tag}_post{i}", (Bt, sizes[i][0], sizes[i][1], ld[i]))
-                self.conv(t, B, gh, gw, hw.act[i][1], u, ws=tag)
+                self.conv(t, B, gh, gw, hw.act[i][1], u, ws=wsn)
             ri = self.hbuf(f"{tag}_rn{i}", (Bt, sizes[i][0], sizes[i][1], Fd))
             # split mode: the producer of an RCU input also writes relu(x) (ufm_conv2d_nhwc_bf16x3 out_relu), which takes
             # the ReLU out of the consumer's MFMA loop; the fp32 kernels apply it on their fragments (relu_in)
             rr = self.hbuf(f"{tag}_rn{i}_relu", (Bt, sizes[i][0], sizes[i][1], Fd)) if self.head_split else None
-            self.conv(u, B, sizes[i][0], sizes[i][1], hw.rn[i], ri, out_relu=rr, ws=tag)
-            r.append((ri, rr))
+            self.conv(u, B, sizes[i][0], sizes[i][1], hw.rn[i], ri, out_relu=rr, ws=wsn)
+            return (ri, rr)
+
+        # The four level chains are independent until the fusion blocks meet them (coarse to fine).  At one or two pairs their
+        # layers are latency-bound grids of a few dozen tiles: levels 2, 1, 0 run on three side streams (graph branches under
+        # hipGraph capture) while this stream does level 3 and starts the fusion; every side stream is joined back right before
+        # its level is read.  Bit-identical (same kernels on the same buffers).
+        cur = torch.cuda.current_stream(self.dev)
+        use_ls = self.level_streams and Bt <= self.level_streams_max_images and hip.TIMER is None
+        r: List[Any] = [None] * 4
+        lst: List[torch.cuda.Stream] = []
+        if use_ls:
+            lst = self._level_streams.setdefault((getattr(self._tls, "ns", ""), tag), [])
+            while len(lst) < 3:
+                lst.append(torch.cuda.Stream(device=self.dev))
+            # fork_from: the stream this head's own stream was forked from (two-stream heads).  The level chains depend on the pyramid
+            # only, so they fork from THAT stream: under hipGraph capture every fork then starts at the capture's origin stream --
+            # a fork from an already forked stream (a nested fork) makes hipStreamEndCapture segfault on ROCm 7 (round-3 crash,
+            # reproduced and bisected in round 4: tools/lab/capture_debug.py, profiles/r04/capture_nested_fork.log)
+            src_stream = fork_from if fork_from is not None else cur
+            for k, i in enumerate((2, 1, 0)):
+                lst[k].wait_stream(src_stream)
+                with torch.cuda.stream(lst[k]):
+                    r[i] = chain(i)
+            r[3] = chain(3)
+        else:
+            for i in range(4):
+                r[i] = chain(i)
 
         def rcu(xs, pair, h, w, name, extra_res=None, want_relu=False):
             """[U] ResidualConvUnit: conv2(relu(conv1(relu(x)))) + x (+ extra_res).  xs = (x, relu(x) or None)."""
@@ -742,6 +775,8 @@ class Engine:
         for lvl in (3, 2, 1, 0):
             h, w = sizes[lvl]
             f = hw.fuse[lvl]
+            if use_ls and lvl < 3:
+                cur.wait_stream(lst[2 - lvl])  # level `lvl` ran on side stream 2 - lvl
             if path is None:
                 s = r[lvl]
             else:
@@ -1166,10 +1201,10 @@ class Engine:
         info_v1, info_v2, info_all = info_tabs if info_tabs is not None else (None, None, None)
         out: Dict[str, Any] = {}
 
-        def run_head(hw, tag):
+        def run_head(hw, tag, fork_from=None):
             if isinstance(hw, _MoGeHead):
                 return self._head_moge(hw, tag, levels, B, gh, gw, H, W)
-            return self._head(hw, tag, levels, dims, B, gh, gw, H, W)
+            return self._head(hw, tag, levels, dims, B, gh, gw, H, W, fork_from=fork_from)
 
         hlist = list(self.heads.values())
         if (self.group_heads and len(hlist) > 1 and self.head_split and _HeadG.compatible(hlist) and hlist[0].p_conv1.cout == 128
@@ -1195,7 +1230,7 @@ class Engine:
             for (tag, hw), st in zip(tags[1:], side_streams):
                 st.wait_stream(main)
                 with torch.cuda.stream(st):
-                    out[tag] = run_head(hw, tag)
+                    out[tag] = run_head(hw, tag, fork_from=main)
             out[tags[0][0]] = run_head(tags[0][1], tags[0][0])
             for (tag, _), st in zip(tags[1:], side_streams):
                 main.wait_stream(st)

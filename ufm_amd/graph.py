@@ -39,6 +39,7 @@ class GraphedPredictor:
         if shared is not None:
             eng.concurrent_heads, eng.fused_tail = shared.concurrent_heads, shared.fused_tail
             eng.group_heads, eng.last_layer_view1, eng.conv_splitk = shared.group_heads, shared.last_layer_view1, shared.conv_splitk
+            eng.level_streams, eng.level_streams_max_images = shared.level_streams, shared.level_streams_max_images
         eng.micro_batches = 1  # one stream, one host thread: the capture records a single linear launch sequence
         model._engine = eng
         try:
