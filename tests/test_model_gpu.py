@@ -765,6 +765,20 @@ def test_hip_graph_survives_eager_calls_with_other_shapes_and_numerics(env):
         next(prod.parameters()).add_(0.0)  # bumps the parameter's version: the packed weights in the graph are stale now
     with pytest.raises(RuntimeError, match="parameters changed"):
         gp(a, b)
+    # the eager engine's cached parameter list: an in-place edit and a swapped-in Parameter OBJECT both re-pack the weights
+    before = prod.predict_correspondences_batched(a, b).flow.flow_output.clone()
+    last = prod.head1[0][1].conv2[2]  # the flow head's final 1x1 convolution
+    orig_bias = last.bias.detach().clone()
+    with torch.no_grad():
+        last.bias.add_(1.0)
+    moved = prod.predict_correspondences_batched(a, b).flow.flow_output
+    assert (moved - before).abs().min().item() > 0.5  # every flow value moved by the bias
+    last.bias = torch.nn.Parameter(orig_bias.clone())  # a NEW Parameter object with the old values
+    assert torch.equal(prod.predict_correspondences_batched(a, b).flow.flow_output, before)
+    gp2 = ufm_amd.GraphedPredictor(prod, a, b)
+    last.bias = torch.nn.Parameter(last.bias.detach().clone())
+    with pytest.raises(RuntimeError, match="parameters changed"):
+        gp2(a, b)
 
 
 def test_hip_graph_capture_with_level_chain_branches_inside_the_two_stream_heads(env):

@@ -64,6 +64,17 @@ class _Lin:
 
 LOG2E = 1.4426950408889634
 
+# Bumped whenever a Parameter is registered on any nn.Module (torch's global hook: also fires for ``module.weight = nn.Parameter(..)``):
+# the engines cache their model's Parameter objects and re-walk the module tree only when this moved.
+PARAM_EPOCH = [0]
+
+
+def _on_parameter_registration(module, name, param):  # noqa: ARG001
+    PARAM_EPOCH[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_on_parameter_registration)
+
 
 class _Blk:
     def __init__(self, blk, dev, wdt, split: bool = False):
@@ -328,12 +339,21 @@ class Engine:
     # ------------------------------------------------------------------ packing
     def _pack(self) -> None:
         m = self.model
-        dev = next(m.parameters()).device
+        # This guard runs in front of EVERY forward: walking the module tree three times (m.parameters()) cost 0.7-1.7 ms of host time
+        # per call -- part of the one-pair eager latency.  The Parameter objects are cached; the tree is walked again only after a
+        # Parameter was (re-)registered on ANY module (PARAM_EPOCH: torch's global parameter-registration hook), i.e. when a Parameter
+        # object may have been swapped into a sub-module; in-place edits, load_state_dict and .to() show in version / address below.
+        plist = getattr(self, "_plist", None)
+        if plist is None or self._plist_epoch != PARAM_EPOCH[0]:
+            plist = self._plist = list(m.parameters())
+            self._plist_epoch = PARAM_EPOCH[0]
+        dev = plist[0].device
         if dev.type != "cuda":
             raise RuntimeError("ufm_amd runs on an AMD GPU only: move the model with .to('cuda') (no CPU fallback exists)")
-        key = (str(dev), self.numerics, tuple(p._version for p in m.parameters()), tuple(p.data_ptr() for p in m.parameters()))
+        key = (str(dev), self.numerics, tuple((p._version, p.data_ptr()) for p in plist))
         if key == self._packed_key:
             return
+
         self.dev = dev
         self._tables.clear()
         self._bufs.clear()

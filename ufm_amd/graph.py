@@ -57,12 +57,21 @@ class GraphedPredictor:
             model._engine = shared  # eager calls go back to the shared engine (created on demand if there was none)
         # The guard below runs on EVERY replay, in front of the graph launch: walking the module tree (model.parameters()) cost
         # 0.3-0.9 ms of host time per call, 4-9 % of the one-pair latency; reading version + address of a cached list costs 0.08 ms.
-        # (Caveat of the cached list: a Parameter OBJECT swapped into a sub-module after the capture is not seen; in-place edits,
-        # load_state_dict and .to() are.  Edits made through ``p.data`` never bump ``_version`` either way.)
+        # A Parameter OBJECT swapped into a sub-module after the capture shows in engine.PARAM_EPOCH (torch's global
+        # parameter-registration hook); in-place edits, load_state_dict and .to() in version / address.  (Edits made through ``p.data``
+        # bump nothing: they are invisible to any guard.)
+        from .engine import PARAM_EPOCH
+
+        self._epoch_ref, self._epoch = PARAM_EPOCH, PARAM_EPOCH[0]
         self._plist = list(self.model.parameters())
         self._weights_key = self._params_key()
 
     def _params_key(self):
+        if self._epoch_ref[0] != self._epoch:  # a Parameter was registered somewhere (any module, any model): is it one of ours?
+            fresh = list(self.model.parameters())
+            if len(fresh) != len(self._plist) or any(a is not b for a, b in zip(fresh, self._plist)):
+                return None  # never equal to the captured key
+            self._epoch = self._epoch_ref[0]
         return tuple((p._version, p.data_ptr()) for p in self._plist)
 
     def __call__(self, source_image: torch.Tensor, target_image: torch.Tensor) -> UFMOutputInterface:
