@@ -28,3 +28,11 @@ pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
 st.sort_stats("cumulative").print_stats(28)
+
+# sanity of ufm_amd.hip._stream(): the raw accessor returns the handle of torch's current stream, also inside a stream context
+from ufm_amd import hip as _hip
+assert _hip._stream() == torch.cuda.current_stream().cuda_stream
+_s = torch.cuda.Stream()
+with torch.cuda.stream(_s):
+    assert _hip._stream() == _s.cuda_stream == torch.cuda.current_stream().cuda_stream
+print("raw stream accessor agrees with torch.cuda.current_stream()")

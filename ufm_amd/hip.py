@@ -137,6 +137,12 @@ class KernelTimer:
 
 TIMER: Optional[KernelTimer] = None
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+if _raw_stream is None or _cur_device is None:  # an older / newer torch without the accessors: the public (slower) route
+    _raw_stream = lambda dev: torch.cuda.current_stream(dev).cuda_stream  # noqa: E731
+    _cur_device = torch.cuda.current_device
+
 
 def _check(rc: int, name: str) -> None:
     if TIMER is not None and TIMER._open is not None and TIMER._open[0] == name:
@@ -152,7 +158,10 @@ def _t(name: str, meta=None) -> None:
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of torch's current HIP stream on the current device.  torch.cuda.current_stream() builds a Stream object through
+    four layers of device-index helpers -- 8 us x ~700 launches = 40 % of the host time of a one-pair forward (cProfile,
+    tools/lab/host_profile_b1.py); the C accessor below returns the same handle (it is what torch's own compiled graphs use)."""
+    return _raw_stream(_cur_device())
 
 
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:
