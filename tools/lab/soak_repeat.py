@@ -32,3 +32,13 @@ soak(r, 8, "UFM-Refine B=8 fast (joint heads)")
 del r
 m = ufm_amd.UniFlowMatchConfidence(**ufm_amd.ufm_base_config()).eval(); init_weights_(m, 0); m = m.to("cuda").set_numerics("precise")
 soak(m, 8, "UFM-Base B=8 precise")
+# round 4: the options that are off by default -- grouped head launches, split-K (agent-scope arrival counters), level-chain streams
+del m
+m = ufm_amd.UniFlowMatchConfidence(**ufm_amd.ufm_base_config()).eval(); init_weights_(m, 0); m = m.to("cuda")
+e = m.engine()
+e.group_heads, e.conv_splitk = True, True
+soak(m, 8, "UFM-Base B=8 fast, grouped heads + split-K")
+e.group_heads = False
+soak(m, 3, "UFM-Base B=3 fast, split-K, two-stream heads")
+e.conv_splitk, e.level_streams, e.level_streams_max_images = False, True, 8
+soak(m, 2, "UFM-Base B=2 fast, level-chain streams")
