@@ -213,6 +213,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    # UFM_BENCH_SHARE_GPU=1 + UFM_BENCH_BACKEND=gloo: a FUNCTIONAL rehearsal of N > 1 on a one-GPU box (all ranks on cuda:0, the
+    # device buffers gathered through gloo; RCCL refuses two ranks on one device).  Never a measurement: the line says so.
+    share_gpu = os.environ.get("UFM_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -226,7 +231,10 @@ def main():
         if world == 1:  # UFM_BENCH_FORCE_DIST=1 without a launcher: a one-rank group on the real backend
             for k_, v_ in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_PORT", "29533")):
                 os.environ.setdefault(k_, v_)
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if os.environ.get("UFM_BENCH_BACKEND") == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
     # Host threads: every rank runs 2 Python launch threads (the two micro-batch streams).  With N ranks on one node the
     # intra-op pools of torch / OpenMP must not multiply on top of that (8 ranks x a 256-thread pool); only rank 0 at N = 1
     # runs the CPU-oracle leg, which sizes its own pool (host_cores()).
@@ -347,6 +355,9 @@ def main():
             "micro_batches_per_gpu": args.micro_batches,
         },
     }
+    if share_gpu:
+        line["config"]["rehearsal"] = f"{world} ranks SHARING one GPU over gloo: functional rehearsal of the N > 1 path, not a measurement"
+        line["metric"] += " [REHEARSAL: ranks share one GPU]"
     if variant:  # NOT the headline configuration: a side measurement of a SURVEY 8(f)4 variant
         line["config"]["variant"] = ", ".join(variant)
         line["metric"] += " [variant: " + ", ".join(variant) + "]"

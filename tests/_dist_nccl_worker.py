@@ -14,9 +14,16 @@ sys.path.insert(0, ROOT)
 
 def main():
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+    backend = os.environ.get("UFM_DIST_BACKEND", "nccl")
+    if backend == "gloo":  # several ranks SHARING one GPU (the lease boxes have one): device tensors gathered through gloo
+        local = 0
+        torch.set_num_threads(2)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist.init_process_group("nccl", device_id=dev)
+    if backend == "gloo":
+        dist.init_process_group("gloo")
+    else:
+        dist.init_process_group("nccl", device_id=dev)
     import ufm_amd
     from ufm_amd.dist import ShardedPredictor, predict_sharded
     from ufm_amd.modules import init_weights_
@@ -46,7 +53,7 @@ def main():
     torch.cuda.synchronize()
     dist.barrier()
     if rank == 0:
-        print(f"DIST-NCCL-OK world={world}")
+        print(f"DIST-{backend.upper()}-OK world={world}")
     dist.destroy_process_group()
 
 

@@ -26,3 +26,22 @@ def test_predict_sharded_on_rccl_equals_unsharded():
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert f"DIST-NCCL-OK world={n}" in r.stdout
+
+
+def test_three_ranks_sharing_the_one_gpu_over_gloo_equal_unsharded():
+    """More than one rank of the N > 1 path with REAL device compute on a one-GPU box: three processes share cuda:0 (RCCL refuses
+    two ranks on one device, so the gather of the device buffers goes through gloo).  Every rank computes its shard with the HIP
+    kernels, the packed device results are gathered, and each rank checks gathered == its own unsharded run bit for bit -- the
+    synchronous form, the asynchronous ring (flag rows through the side stream + pinned host buffer) and the fewer-pairs-than-ranks
+    case.  A functional rehearsal, not a measurement."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", UFM_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "_dist_nccl_worker.py")]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "DIST-GLOO-OK world=3" in r.stdout

@@ -827,6 +827,35 @@ def test_bench_n_gt_1_branch_rehearsed_on_one_rank_over_rccl():
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] == "weak"
 
 
+def test_bench_two_ranks_sharing_the_gpu_gather_and_cross_check_each_other():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank) on a one-GPU box: both ranks on
+    cuda:0, device buffers gathered through gloo (UFM_BENCH_SHARE_GPU / UFM_BENCH_BACKEND; RCCL refuses two ranks on one device).
+    Rank r recomputes a pair of rank (r + 1) % 2's shard and compares it with what the gather delivered, bit for bit -- the
+    cross-rank check that a one-rank group cannot exercise.  A functional rehearsal; the line is labelled as such."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    envv = dict(os.environ, UFM_BENCH_SHARE_GPU="1", UFM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "UFM_BENCH_FORCE_DIST"):
+        envv.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2",
+           "--no-cpu-baseline", "--no-parity-mode", "--no-precise-mode", "--no-latency", "--no-kernel-timing"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=envv, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and "REHEARSAL" in line["metric"]
+    assert line["gather_check"] == {"bitwise_equal_to_local_recompute": True, "pairs_gathered": 4}
+    assert len(line["per_rank_ms_per_step"]["all"]) == 2 and line["host_threads_per_rank"]["torch_intra_op"] == 2
+    assert line["summary"]["gather_check"]["bitwise_equal_to_local_recompute"] is True
+
+
 def _cov_conf_config(mod):
     """Tiny model whose uncertainty head carries all three named outputs of ufm.py:644-660."""
     cfg = mod.ufm_tiny_config()
