@@ -135,14 +135,24 @@ int ufm_cross_attention_bf16x3(const uint16_t* q, int ldq, const uint16_t* k, co
  * that fill whole rounds of the chip + 128x128 on the rest).  flags (timing diagnostics, results are wrong): 2 = no DMA,
  * 4 = no epilogue traffic, 8 = direct (un-staged) epilogue of the 128x128 kernel (results right), 16 / 32 = lda / ldw taken
  * as 0 (cache-hit probe), bits 8..15 = grouped-rasterization height of the 8-phase kernel (results right).
- * tile_rows: 0 = cost model, 160 / 192 / 224 / 256 = pin the row height of the 8-phase tiles (results are bitwise the same). */
+ * tile_rows: 0 = cost model, 160 / 192 / 224 / 256 = pin the row height of the 8-phase tiles (results are bitwise the same).
+ * Round 5: variant 6 = the 256x128 four-wave kernel with two resident workgroups per CU (gemm_bf16_pair.hip; any N % 128 == 0,
+ * K >= 128; bitwise the other kernels); flags bits 16..22 = first-round start delay of a CU's second resident workgroup in
+ * that kernel (units of s_sleep(64); results right). */
 int ufm_debug_set_gemm_variant(int variant);
 int ufm_debug_set_gemm_flags(int flags);
 int ufm_debug_set_gemm_tile_rows(int rows);
+/* In-kernel stamps of the 8-phase and pair GEMM kernels (diagnostic instantiations; the shipped kernels execute no stamp):
+ * while `buf` is set, launches with the fc1 (bias + GELU -> bf16) or proj / fc2 (bias + LayerScale + fp32 residual) epilogue
+ * write 8 x uint64 per workgroup b < rows: {b | HW_ID << 32, XCC_ID | LDS_ALLOC << 32, s_memtime at entry, after the K loop,
+ * after the last store completed, s_memrealtime (100 MHz) at entry, at the end, s_memtime after the prologue}.  The buffer
+ * is read by no kernel.  buf = NULL, rows = 0 turns it off.  tools/lab/gemm_stamps.py. */
+int ufm_debug_set_gemm_stamps(unsigned long long* buf, int rows);
 /* Tuning hook for ufm_attention_bf16 (scale == 0 form): 0 = 4 waves per workgroup (default), 1 = 2 waves per workgroup. */
 int ufm_debug_set_attn_variant(int v);
 /* Tuning hook for ufm_conv2d_nhwc_bf16x3: 0 = auto, 1 = 128-row kernels only, 2 = 256x256 8-phase kernel wherever applicable,
- * 3 = 128-row kernels only and never the deep (4-stage) ring. */
+ * 3 = 128-row kernels only and never the deep (4-stage) ring; + 16 = the serial per-pass residual read-out of rounds 1-4 in the
+ * epilogue instead of round 5's grouped loads (bitwise the same results; A/B). */
 int ufm_debug_set_conv_variant(int v);
 /* Tuning hook for ufm_upsample_bilinear_nhwc (split format): 1 = LDS-tiled kernel where applicable (default), 0 = never. */
 int ufm_debug_set_upsample_variant(int tiled);

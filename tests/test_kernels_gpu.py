@@ -107,11 +107,13 @@ def test_gemm_128_two_k_tiles_per_barrier_is_bit_identical(hip, M, N, K):
     assert (outs[0][0] - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("M,N,K", [(256 * 9 + 77, 1024, 128), (256 * 7, 1024, 192), (5000, 2304, 768), (4 * 1370, 1024, 4096), (300, 256, 1024), (8 * 1369, 768, 768)])
+@pytest.mark.parametrize("M,N,K", [(256 * 9 + 77, 1024, 128), (256 * 7, 1024, 192), (5000, 2304, 768), (4 * 1370, 1024, 4096), (300, 256, 1024), (8 * 1369, 768, 768),
+                                   (256 * 5 + 3, 640, 256), (2000, 384, 320), (1370 * 3, 1024, 448), (777, 128, 832)])
 def test_gemm_8phase_bitwise_equals_128_kernel_repeated(hip, M, N, K):
-    """Race screen for the counted-vmcnt schedule: the 8-phase kernel (variant 4) and the hybrid split (5) accumulate in
-    the same K order as the 128x128 kernel (1), so all three must agree BIT FOR BIT -- over repeated launches (a DMA
-    that lands late shows up as a rare wrong tile), K-tile counts 2 (prologue + drain only), 3 (odd), 12, 64, ragged M."""
+    """Race screen for the counted-vmcnt schedule: the 8-phase kernel (variant 4), the hybrid split (5) and the 256x128
+    two-resident-workgroups kernel (6, round 5) accumulate in the same K order as the 128x128 kernel (1), so all must agree
+    BIT FOR BIT -- over repeated launches (a DMA that lands late shows up as a rare wrong tile), K-tile counts 2 (prologue +
+    drain only), 3 (odd), 4, 5, 7, 12, 13, 16, 64 (every exit of the pair kernel's six-body loop), ragged M, N % 256 != 0."""
     lib = hip.lib()
     A = bf16r(rnd(M, K, seed=1)).to(DEV).bfloat16()
     W = bf16r(rnd(N, K, seed=2, scale=K**-0.5)).to(DEV).bfloat16()
@@ -132,9 +134,14 @@ def test_gemm_8phase_bitwise_equals_128_kernel_repeated(hip, M, N, K):
         # (variant, pinned tile rows): the 8-phase kernel at its four tile heights (160 / 192 / 224 rows skip the MFMA
         # fragments past the tile's end; ragged last tiles at every height), the hybrid split and the cost model's own pick
         for rep in range(3):
-            for variant, rows in ((4, 256), (4, 224), (4, 192), (4, 160), (5, 0), (0, 0)):
+            # (1, -128): the 128x128 kernel with the SERIAL read-modify-write read-out of rounds 1-4 (flag 0x800000) -- `want` above comes
+            # from round 5's pipelined one (residual loads out of the store chain, gemm_common.h epilogue_lds_rmw2): same bits
+            for variant, rows in ((4, 256), (4, 224), (4, 192), (4, 160), (5, 0), (0, 0), (6, 0), (6, -3), (1, -128), (4, -128), (6, -128)):
+                if variant in (4, 5) and N % 256:
+                    continue
                 lib.ufm_debug_set_gemm_variant(variant)
-                lib.ufm_debug_set_gemm_tile_rows(rows)
+                lib.ufm_debug_set_gemm_tile_rows(max(rows, 0))
+                lib.ufm_debug_set_gemm_flags((-rows) << 16 if rows < 0 else 0)  # (6, -3): second resident workgroups start 3 sleeps late; -128 << 16 = 0x800000
                 got = torch.full((M, N), 3.0, device=DEV)
                 hip.gemm_bf16(A, W, M, N, K, got, bias=bias, res=res)
                 assert torch.equal(got, want), (variant, rows, rep)
@@ -151,6 +158,7 @@ def test_gemm_8phase_bitwise_equals_128_kernel_repeated(hip, M, N, K):
     finally:
         lib.ufm_debug_set_gemm_variant(0)
         lib.ufm_debug_set_gemm_tile_rows(0)
+        lib.ufm_debug_set_gemm_flags(0)
 
 
 def test_gemm_8phase_tile_heights_with_row_tables(hip):
@@ -971,6 +979,15 @@ def test_gemm_bf16x3(hip, M, N, K, act, use_gamma, use_res, split_out):
     err = (got - ref).abs().max().item()
     # dropped lo*lo terms 2^-16 per product (random signs), fp32 accumulation over K, split store 2^-17
     assert err <= 4e-5 * max(1.0, ref.abs().max().item()), err
+    if use_res:  # round 5: the grouped residual loads of the epilogue against the serial per-pass read-out (variant + 16), bit for bit
+        lib = hip.lib()
+        try:
+            lib.ufm_debug_set_conv_variant(16)
+            out2 = res.to(DEV).clone()
+            hip.gemm_x3(As.to(DEV), Ws.to(DEV), M, N, K, out2, zero, bias=bias.to(DEV), act=act, gamma=gamma.to(DEV) if gamma is not None else None, res=out2)
+        finally:
+            lib.ufm_debug_set_conv_variant(0)
+        assert torch.equal(out2, out)
 
 
 def test_split_format_gelu_epilogue_against_fp64_gelu(hip):
@@ -1086,6 +1103,8 @@ def test_conv2d_single_pass_is_a_bf16_convolution(hip, B, H, W, Cin, Cout, k, st
         (2, 30, 30, 96, 384, 3, 2, 1, False, 2, 0, 0),    # Cout = 384 = 3 x 128: three column tiles of the 512 x 128 layout, stride 2
         (1, 30, 30, 256, 64, 3, 1, 1, True, 0, 2, 0),     # 15 blocks of 64x64, 72 K-tiles, both residuals
         (1, 9, 7, 32, 64, 1, 1, 0, False, 0, 0, 0),       # a single K-tile (nk = 1 < ring depth)
+        (4, 74, 74, 64, 256, 3, 1, 1, True, 0, 2, 0),     # whole 8-phase tiles with BOTH residuals: the grouped loads in two groups of 8 passes
+        (8, 37, 37, 64, 256, 3, 1, 1, False, 2, 1, 0),    # one residual + output ReLU (the -inf / 0 clamp of the grouped path)
     ],
 )
 def test_conv2d_bf16x3_8phase_bit_identical(hip, B, H, W, Cin, Cout, k, stride, pad, relu_in, act, nres, shuffle):
@@ -1102,7 +1121,9 @@ def test_conv2d_bf16x3_8phase_bit_identical(hip, B, H, W, Cin, Cout, k, stride, 
     zero = torch.zeros(256, device=DEV)
     outs = {}
     try:
-        for variant in (3, 1, 2, 0):  # 3 = 128-row kernels with the plain 2-stage loop only: the baseline
+        # 19 = 3 + 16: the plain 2-stage 128-row kernels with the SERIAL per-pass residual read-out of rounds 1-4: the baseline that
+        # round 5's grouped-load epilogue (conv_x3_common.h) must reproduce bit for bit in every kernel
+        for variant in (19, 3, 1, 2, 0):
             lib.ufm_debug_set_conv_variant(variant)
             out = torch.full(oshape, 7.0, device=DEV, dtype=torch.bfloat16)
             orl = None if shuffle else torch.full(oshape, 7.0, device=DEV, dtype=torch.bfloat16)
@@ -1111,10 +1132,10 @@ def test_conv2d_bf16x3_8phase_bit_identical(hip, B, H, W, Cin, Cout, k, stride, 
             outs[variant] = (out.cpu(), None if shuffle else orl.cpu())
     finally:
         lib.ufm_debug_set_conv_variant(0)
-    for v in (1, 2, 0):
-        assert torch.equal(outs[3][0].view(torch.int16), outs[v][0].view(torch.int16))
+    for v in (3, 1, 2, 0):
+        assert torch.equal(outs[19][0].view(torch.int16), outs[v][0].view(torch.int16)), v
         if not shuffle:
-            assert torch.equal(outs[3][1].view(torch.int16), outs[v][1].view(torch.int16))
+            assert torch.equal(outs[19][1].view(torch.int16), outs[v][1].view(torch.int16)), v
     if not shuffle:  # the second output is relu(out), exactly (what relu_in=1 would apply by the sign of hi)
         assert torch.equal(unsplit(outs[3][1]), torch.relu(unsplit(outs[3][0])))
 

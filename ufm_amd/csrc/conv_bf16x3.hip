@@ -244,11 +244,11 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void conv_x3_kernel(ConvX3Arg
 
 }  // namespace
 
-static int g_conv_variant = 0;
+static int g_conv_variant_all = 0;
 // test/tuning hook: 0 = auto, 1 = 128-row kernels only, 2 = 8-phase kernel wherever it is applicable,
-// 3 = 128-row kernels only and never the deep (NS = 4) ring
+// 3 = 128-row kernels only and never the deep (NS = 4) ring; + 16 = the serial (per-pass) residual read-out of rounds 1-4
 extern "C" int ufm_debug_set_conv_variant(int v) {
-    g_conv_variant = v;
+    g_conv_variant_all = v;
     return UFM_OK;
 }
 
@@ -277,7 +277,10 @@ extern "C" long long ufm_conv_x3_splitk_ws_bytes(int groups, int B, int H, int W
 }
 
 // Kernel choice for one problem (shared by the convolution and the Linear entry points).
-static void launch_conv_x3(const ConvX3Args& p, int passes, hipStream_t stream) {
+static void launch_conv_x3(const ConvX3Args& p_in, int passes, hipStream_t stream) {
+    ConvX3Args p = p_in;
+    p.serial_epilogue = (g_conv_variant_all >> 4) & 1;
+    const int g_conv_variant = g_conv_variant_all & 15;
     const int Cout = p.Cout, KH = p.KH, KW = p.KW, Cin = p.Cin;
     const long long M = p.M;
     const int S = p.splitk;

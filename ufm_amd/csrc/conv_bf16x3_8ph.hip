@@ -245,9 +245,9 @@ __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
 
     if (wr == 0) __builtin_amdgcn_s_barrier();  // pairs with the last M-slot barrier of the wr = 1 group
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-        conv_x3_epilogue<4, 4>(p, acc[h], smem + wave * 16384, m0 + wr * 128 + h * 64, n0 + wc * 64, lane, grp);
+    // two explicit calls: a loop over h that hipcc declines to unroll would index acc[h] at run time -> scratch (rule 20)
+    conv_x3_epilogue<4, 4>(p, acc[0], smem + wave * 16384, m0 + wr * 128, n0 + wc * 64, lane, grp);
+    conv_x3_epilogue<4, 4>(p, acc[1], smem + wave * 16384, m0 + wr * 128 + 64, n0 + wc * 64, lane, grp);
 }
 
 }  // namespace

@@ -34,6 +34,7 @@ struct ConvX3Args {
     int splitk;
     float* slab;          // [tiles][splitk][BM * BN] partial tiles (fragment order)
     unsigned* counters;   // [tiles], zero between launches (the last arriver resets its tile's word)
+    int serial_epilogue;  // A/B hook (ufm_debug_set_conv_variant bit 4): the per-pass residual read-out of rounds 1-4
 };
 
 // tile row index over all groups -> (group, tile row inside the group); tiles_pg = row tiles per group of this launch
@@ -96,8 +97,76 @@ static __device__ __forceinline__ void conv_x3_epilogue(const ConvX3Args& p, f32
         }
     }
     const int orr = lane / LPR, oc = lane % LPR;
+    // Round 5: residual epilogues with the loads taken OUT of the store chain.  The general loop below compiles to {residual
+    // loads, s_waitcnt vmcnt(0), stores} per pass -- `continue` / run-time switches keep hipcc from moving a load above the
+    // previous pass's stores, and a vmcnt(0) also waits for those STORES (vmcnt counts them): 16 serial memory round trips per
+    // 64-row slice.  For whole slices (no ragged rows, no pixel shuffle) of the three residual forms -- fp32 read-modify-write
+    // (ufm_gemm_bf16x3's proj / fc2), one or two split residuals (the RCU / fusion-block convolutions) -- the loads of a group of
+    // passes are issued first, then the group's arithmetic and stores.  Same operations in the same order per element: bit-identical.
+    constexpr int PASSES = TM * 16 / RPI;
+    const int mode = (p.shuffle || pix0 + TM * 16 > p.M || p.act == UFM_ACT_GELU) ? 0
+                     : (p.out_f32 ? (p.res_f32 ? 3 : 0) : (p.res1 ? (p.res2 ? 2 : 1) : 0));
+    if (mode != 0 && !p.serial_epilogue) {
+        const int cb = cb0 + oc * 4;
+        const float lo = (p.act == UFM_ACT_RELU) ? 0.0f : -__builtin_inff();  // fmaxf(v, -inf) == v
+        f32x4 gv = {1.f, 1.f, 1.f, 1.f};
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // compiler-visible vmcnt(0): clears the K loop's LDS-DMA from hipcc's scoreboard (all landed)
+        if (p.gamma) gv = *(const f32x4*)(p.gamma + cb);
+        auto body = [&](auto mode_c) {
+            constexpr int MODE = decltype(mode_c)::value;
+            constexpr int G = MODE == 2 ? (PASSES < 8 ? PASSES : 8) : PASSES;  // passes per group: <= 64 registers of loads in flight
 #pragma unroll
-    for (int pass = 0; pass < TM * 16 / RPI; ++pass) {
+            for (int g0 = 0; g0 < PASSES; g0 += G) {
+                f32x4 rf[G];
+                u32x2 h1[G], l1[G], h2[MODE == 2 ? G : 1], l2[MODE == 2 ? G : 1];
+#pragma unroll
+                for (int i = 0; i < G; ++i) {
+                    const size_t o = (size_t)(row0 + pix0 + (g0 + i) * RPI + orr) * p.Cout + cb;
+                    if constexpr (MODE == 3) rf[i] = *(const f32x4*)(p.res_f32 + o);
+                    if constexpr (MODE == 1 || MODE == 2) h1[i] = *(const u32x2*)(p.res1 + o), l1[i] = *(const u32x2*)(p.res1 + o + p.out_plane);
+                    if constexpr (MODE == 2) h2[i] = *(const u32x2*)(p.res2 + o), l2[i] = *(const u32x2*)(p.res2 + o + p.out_plane);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < G; ++i) {
+                    const int r = (g0 + i) * RPI + orr;
+                    const size_t o = (size_t)(row0 + pix0 + r) * p.Cout + cb;
+                    f32x4 v = *(const f32x4*)(ws + r * ROWB + ((oc ^ (r & (NCH - 1))) << 4));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], lo);
+                    v *= gv;
+                    auto unsplit = [](const u32x2& ph, const u32x2& pl) {
+                        f32x4 x;
+                        x[0] = __uint_as_float(ph[0] << 16) + __uint_as_float(pl[0] << 16);
+                        x[1] = __uint_as_float(ph[0] & 0xffff0000u) + __uint_as_float(pl[0] & 0xffff0000u);
+                        x[2] = __uint_as_float(ph[1] << 16) + __uint_as_float(pl[1] << 16);
+                        x[3] = __uint_as_float(ph[1] & 0xffff0000u) + __uint_as_float(pl[1] & 0xffff0000u);
+                        return x;
+                    };
+                    if constexpr (MODE == 3) {
+                        v += rf[i];
+                        *(f32x4*)(p.out_f32 + o) = v;
+                    } else {
+                        v += unsplit(h1[i], l1[i]);
+                        if constexpr (MODE == 2) v += unsplit(h2[i], l2[i]);
+                        split_store4(p.out + o, p.out_plane, v);
+                        if (p.out_relu) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+                            split_store4(p.out_relu + o, p.out_plane, v);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (mode == 3) body(std::integral_constant<int, 3>{});
+        else if (mode == 2) body(std::integral_constant<int, 2>{});
+        else body(std::integral_constant<int, 1>{});
+        return;
+    }
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
         const int r = pass * RPI + orr;
         f32x4 v = *(const f32x4*)(ws + r * ROWB + ((oc ^ (r & (NCH - 1))) << 4));
         if (pix0 + r >= p.M) continue;

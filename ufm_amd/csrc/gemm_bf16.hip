@@ -143,6 +143,13 @@ __global__ __launch_bounds__(256, KS == 1 ? 2 : 1) void gemm_bf16_kernel(GemmArg
         return;
     }
     __syncthreads();  // every wave is done reading the staging buffers
+    if constexpr (!OUT_BF16) {
+        // the transformer's read-modify-write form on a whole slice: residual loads out of the store chain (gemm_common.h, round 5)
+        if (p.res && p.bias && p.act == UFM_ACT_NONE && p.res_row_mod == 0 && p.out_row_group == 0 && m0 + wr * 64 + 64 <= p.M && !(p.debug & 0x800000)) {
+            epilogue_lds_rmw2<0, 5>(p, acc, acc, smem + wave * 16384, m0 + wr * 64, n0 + wc * 64, lane);
+            return;
+        }
+    }
     epilogue_lds<OUT_BF16>(p, acc, smem + wave * 16384, m0 + wr * 64, n0 + wc * 64, lane);
 }
 
@@ -151,8 +158,8 @@ __global__ __launch_bounds__(256, KS == 1 ? 2 : 1) void gemm_bf16_kernel(GemmArg
 static int g_gemm_variant = 0;  // 0 auto, 1 = 128x128 kernel, 4 = 256x256 8-phase kernel, 5 = hybrid (8-phase on whole rounds + 128x128 on the rest)
 static int g_gemm_flags = 0;    // diagnostics (tools/): 2 = no DMA, 4 = no epilogue traffic, 8 = direct (un-staged) epilogue of the 128x128 kernel
 extern "C" int ufm_debug_set_gemm_variant(int variant) {
-    if (variant != 0 && variant != 1 && variant != 4 && variant != 5) {
-        ufm_set_error("ufm_debug_set_gemm_variant: %d is not one of 0 (auto), 1 (128x128), 4 (8-phase), 5 (hybrid)", variant);
+    if (variant != 0 && variant != 1 && variant != 4 && variant != 5 && variant != 6) {
+        ufm_set_error("ufm_debug_set_gemm_variant: %d is not one of 0 (auto), 1 (128x128), 4 (8-phase), 5 (hybrid), 6 (256x128 pair)", variant);
         return UFM_ERR_ARG;
     }
     g_gemm_variant = variant;
@@ -167,8 +174,18 @@ extern "C" int ufm_debug_set_gemm_tile_rows(int rows) {
     g_gemm_tile_rows = rows;
     return UFM_OK;
 }
+// Diagnostics (tools/lab/gemm_stamps.py): while a buffer is set, the 8-phase / pair launches that have a stamped instantiation
+// write one 8 x uint64 row per workgroup (gemm_common.h GemmStamps) for workgroups [0, rows); nullptr = off (the default).
+static unsigned long long* g_gemm_stamps = nullptr;
+static int g_gemm_stamp_rows = 0;
+extern "C" int ufm_debug_set_gemm_stamps(unsigned long long* buf, int rows) {
+    UFM_REQUIRE((buf == nullptr) == (rows == 0) && rows >= 0, "ufm_debug_set_gemm_stamps: buffer and row count must be given together");
+    g_gemm_stamps = buf;
+    g_gemm_stamp_rows = rows;
+    return UFM_OK;
+}
 extern "C" int ufm_debug_set_gemm_flags(int flags) {
-    g_gemm_flags = flags & (2 | 4 | 8 | 16 | 32 | 64 | 128 | 0xff00 | 0x70000);  // 0x70000: start stagger of the 8-phase kernel's first round (lab)  // 128: never the two-K-tiles-per-barrier form of the 128x128 kernel  // 64: generic (run-time switched) epilogue in the 8-phase kernels  // 16 / 32: lda / ldw = 0 (every tile reads the same rows: an all-L2-hit probe, tools/lab)
+    g_gemm_flags = flags & (2 | 4 | 8 | 16 | 32 | 64 | 128 | 0xff00 | 0x7f0000 | 0x800000);  // 0x800000: the serial read-modify-write read-out (A/B of round 5's pipelined one)  // 0x70000: start stagger of the 8-phase kernel's first round (lab)  // 128: never the two-K-tiles-per-barrier form of the 128x128 kernel  // 64: generic (run-time switched) epilogue in the 8-phase kernels  // 16 / 32: lda / ldw = 0 (every tile reads the same rows: an all-L2-hit probe, tools/lab)
     return UFM_OK;
 }
 
@@ -201,7 +218,7 @@ extern "C" int ufm_gemm_bf16_rope(const uint16_t* A, int lda, const uint16_t* W,
     UFM_REQUIRE(ldo % 4 == 0 && ldo >= N && (!res || (ldres % 4 == 0 && ldres >= N)), "ufm_gemm_bf16: bad ldo/ldres");
     UFM_REQUIRE(out_dtype == UFM_F32 || out_dtype == UFM_BF16, "ufm_gemm_bf16: bad out_dtype %d", out_dtype);
     UFM_REQUIRE((size_t)M * (size_t)(lda > ldo ? lda : ldo) < (1ull << 40), "ufm_gemm_bf16: problem too large");
-    GemmArgs p{A, W, bias, gamma, res, out, lda, ldw, M, N, K, act, ldres, res_row_mod, ldo, out_row_group, g_gemm_flags, 0, rope_cos, rope_sin, rope_mod, rope_cols};
+    GemmArgs p{A, W, bias, gamma, res, out, lda, ldw, M, N, K, act, ldres, res_row_mod, ldo, out_row_group, g_gemm_flags, 0, rope_cos, rope_sin, rope_mod, rope_cols, g_gemm_stamps, g_gemm_stamp_rows};
     if (g_gemm_flags & 16) p.lda = 0;
     if (g_gemm_flags & 32) p.ldw = 0;
     const int NCU = ufm_device_cu_count();  // whole rounds of the one-block-per-CU 8-phase kernel
@@ -262,6 +279,7 @@ extern "C" int ufm_gemm_bf16_rope(const uint16_t* A, int lda, const uint16_t* W,
         nf_lead = g_gemm_tile_rows / 32;
     }
     if ((variant == 4 || variant == 5) && !ok8) variant = 1;
+    if (variant == 6 && !(K >= 128 && fits32)) variant = 1;
     auto launch128 = [&](const GemmArgs& q) {
         const int ntm = (q.M - q.m_begin + BM - 1) / BM, ntn128 = N / BN;
         dim3 grid(ntm * ntn128), block(256);
@@ -293,6 +311,8 @@ extern "C" int ufm_gemm_bf16_rope(const uint16_t* A, int lda, const uint16_t* W,
         else launch128(rest);
     } else if (variant == 4) {
         ufm_launch_gemm_8ph(p, out_dtype, (hipStream_t)stream, nf_lead, epi);
+    } else if (variant == 6) {
+        ufm_launch_gemm_pair(p, out_dtype, (hipStream_t)stream, epi);
     } else {
         launch128(p);
     }

@@ -35,9 +35,11 @@ using IC = std::integral_constant<int, K>;
 // of it; its second 64-row half simply has NF - 4 fragments).  Lower tiles make ceil(M / height) * (N / 256) fit whole rounds of
 // the chip where 256-row tiles would strand CUs (M = 10 952, N = 1024: 172 tiles on 256 CUs -> 232 tiles of 192 rows).  The
 // staging, the phase schedule and every output element's accumulation order are those of NF = 8.
-template <int OUT_BF16, int NF, int EPI>
+template <int OUT_BF16, int NF, int EPI, bool STAMP = false>
 __device__ __forceinline__ void gemm_bf16_8ph_body(const GemmArgs& p, char* smem) {
     static_assert(NF >= 5 && NF <= 8, "NF");
+    GemmStamps stamps;
+    if constexpr (STAMP) stamps.entry();
     constexpr int RW = 16 * NF, BMT = 2 * RW;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -181,6 +183,7 @@ __device__ __forceinline__ void gemm_bf16_8ph_body(const GemmArgs& p, char* smem
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     read_w(wb, 0, 0);
+    if constexpr (STAMP) stamps.t_prologue = gemm_stamp();
     if (wr == 1) {  // stagger: the wr = 1 group runs one slot behind
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -195,6 +198,7 @@ __device__ __forceinline__ void gemm_bf16_8ph_body(const GemmArgs& p, char* smem
 
     if (wr == 0) __builtin_amdgcn_s_barrier();  // pairs with the last M-slot barrier of the wr = 1 group
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (STAMP) stamps.t_loop = gemm_stamp();
     // every wave has passed its last ds_read and every DMA has landed (the tail waits end at vmcnt(0)):
     // the staging buffers are free for the epilogue, 16 KiB per wave, two 64x64 passes
     if (p.debug & 4) {  // ablation (tools/): no epilogue traffic; keep the accumulators live
@@ -208,14 +212,14 @@ __device__ __forceinline__ void gemm_bf16_8ph_body(const GemmArgs& p, char* smem
         if (keep == 123.456f) ((float*)p.out)[0] = keep;
         return;
     }
-    epilogue_lds<OUT_BF16, 64, EPI>(p, acc[0], smem + wave * 16384, m0 + wr * RW, n0 + wc * 64, lane);
-    epilogue_lds<OUT_BF16, RW - 64, EPI>(p, acc[1], smem + wave * 16384, m0 + wr * RW + 64, n0 + wc * 64, lane);
+    epilogue_two_slices<OUT_BF16, RW - 64, EPI>(p, acc[0], acc[1], smem + wave * 16384, m0 + wr * RW, n0 + wc * 64, lane);
+    if constexpr (STAMP) stamps.finish(p.stamps, p.stamp_rows);
 }
 
-template <int OUT_BF16, int NF, int EPI>
+template <int OUT_BF16, int NF, int EPI, bool STAMP = false>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_8ph_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[8 * HALF];  // [tile & 1][kind]
-    gemm_bf16_8ph_body<OUT_BF16, NF, EPI>(p, smem);
+    gemm_bf16_8ph_body<OUT_BF16, NF, EPI, STAMP>(p, smem);
 }
 
 }  // namespace
@@ -224,6 +228,13 @@ int ufm_launch_gemm_8ph(const GemmArgs& p, int out_dtype, hipStream_t stream, in
     const int bmt = 32 * nf;
     const int ntm = (p.M - p.m_begin + bmt - 1) / bmt, ntn = p.N / 256;
     dim3 grid(ntm * ntn), block(512);
+    if (p.stamps && (nf == 6 || nf == 8) && ((out_dtype == UFM_BF16 && epi == 1) || (out_dtype == UFM_F32 && epi == 3))) {  // diagnostic build
+        if (nf == 6 && epi == 1) hipLaunchKernelGGL((gemm_bf16_8ph_kernel<1, 6, 1, true>), grid, block, 0, stream, p);
+        else if (nf == 6) hipLaunchKernelGGL((gemm_bf16_8ph_kernel<0, 6, 3, true>), grid, block, 0, stream, p);
+        else if (epi == 1) hipLaunchKernelGGL((gemm_bf16_8ph_kernel<1, 8, 1, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((gemm_bf16_8ph_kernel<0, 8, 3, true>), grid, block, 0, stream, p);
+        return 0;
+    }
     // bf16 output: EPI 0 / 1 / 2; fp32 output: EPI 0 / 3 / 4 (gemm_common.h EpiTraits)
 #define UFM_L8E(NF_, OUT_, EPI_) hipLaunchKernelGGL((gemm_bf16_8ph_kernel<OUT_, NF_, EPI_>), grid, block, 0, stream, p)
 #define UFM_L8(NF_)                                                                                   \

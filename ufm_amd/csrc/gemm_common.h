@@ -18,6 +18,9 @@ struct GemmArgs {
     const float* rope_cos;
     const float* rope_sin;
     int rope_mod, rope_cols;
+    // diagnostic builds only (ufm_debug_set_gemm_stamps; the STAMP = true instantiations): 8 x uint64 per workgroup, see gemm_stamp_row
+    unsigned long long* stamps;
+    int stamp_rows;
 };
 
 namespace {
@@ -183,6 +186,128 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs& p, f32x4 (&acc)[4][
 }
 
 
+// The read-modify-write epilogue (EPI 3 / 4: bias [, LayerScale], fp32 residual updated in place) of a wave's TWO 64-column slices
+// (rows [row0, row0 + 64) from acc0, [row0 + 64, row0 + 64 + ROWS1) from acc1) with the residual loads taken out of the store chain.
+// epilogue_lds' read-out compiles to {global_load, s_waitcnt vmcnt(0), add, global_store} x 16 per slice: `res` and `out` are the
+// same buffer, so hipcc may not move load i + 1 above store i, and vmcnt(0) in front of every add also waits for the previous
+// STORE (stores count in vmcnt): 32+ serial memory round trips per wave -- the 28-41 k cycles per tile the stamps show
+// (tools/lab/gemm_stamps.py; round 5).  Every lane reads and writes only its own elements, so here all 16 residual loads of a slice
+// are issued first (the second slice's as soon as acc0's registers are free, i.e. under the first slice's read-out), and the
+// stores follow; the compiler's counted vmcnt waits do the rest.  Only for whole slices (no ragged rows): the caller falls back
+// to epilogue_lds otherwise.  Same arithmetic in the same order as epilogue_lds: bit-identical.
+template <int ROWS1, int EPI>
+__device__ __forceinline__ void epilogue_lds_rmw2(const GemmArgs& p, f32x4 (&acc0)[4][4], f32x4 (&acc1)[4][4], char* wave_lds, int row0, int col0, int lane) {
+    static_assert(EPI == 3 || EPI == 4 || EPI == 5, "read-modify-write epilogues only");  // 5: LayerScale decided at run time (128x128 kernel)
+    static_assert(ROWS1 % 16 == 0 && ROWS1 >= 0 && ROWS1 <= 64, "ROWS1");
+    constexpr bool HAS_GAMMA = EPI == 3 || EPI == 5;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int rr = lane >> 4, c = lane & 15;
+    const int nb = col0 + c * 4;
+    const float* rbase = p.res + (size_t)(row0 + rr) * p.ldres + nb;
+    float* obase = (float*)p.out + (size_t)(row0 + rr) * p.ldo + nb;
+    // A compiler-visible vmcnt(0): the K loop's LDS-DMA waits are inline asm, so hipcc still has the DMAs on its scoreboard and would
+    // put vmcnt(0) -- not a counted wait -- in front of the first use of ANY load result below (they have all landed: free).
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    f32x4 rv0[16], rv1[ROWS1 / 4 > 0 ? ROWS1 / 4 : 1];
+    f32x4 bv[4], gv[4];  // first: vmcnt counts in issue order, and the staging below needs these, not the residual rows
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        bv[n] = *(const f32x4*)(p.bias + col0 + n * 16 + fq * 4);
+        if (EPI == 5) gv[n] = p.gamma ? *(const f32x4*)(p.gamma + col0 + n * 16 + fq * 4) : f32x4{1.f, 1.f, 1.f, 1.f};  // x * 1.0f is exact
+        else if (HAS_GAMMA) gv[n] = *(const f32x4*)(p.gamma + col0 + n * 16 + fq * 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) rv0[i] = *(const f32x4*)(rbase + (size_t)(4 * i) * p.ldres);
+    __builtin_amdgcn_sched_barrier(0);
+    auto stage = [&](f32x4 (&acc)[4][4], auto rows_c) {
+        constexpr int ROWS = decltype(rows_c)::value;
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int m = 0; m < ROWS / 16; ++m) {
+                f32x4 v = acc[n][m] + bv[n];
+                if (HAS_GAMMA) v *= gv[n];
+                const int r = m * 16 + fr;
+                *(f32x4*)(wave_lds + r * 256 + (((n * 4 + fq) ^ (r & 15)) << 4)) = v;
+            }
+    };
+    stage(acc0, std::integral_constant<int, 64>{});
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (ROWS1 > 0) {  // the second slice's residual rows, into the registers acc0 just left
+#pragma unroll
+        for (int i = 0; i < ROWS1 / 4; ++i) rv1[i] = *(const f32x4*)(rbase + (size_t)(64 + 4 * i) * p.ldres);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = 4 * i + rr;
+        f32x4 v = *(const f32x4*)(wave_lds + r * 256 + ((c ^ (r & 15)) << 4));
+        v += rv0[i];
+        *(f32x4*)(obase + (size_t)(4 * i) * p.ldo) = v;
+    }
+    if constexpr (ROWS1 > 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        stage(acc1, std::integral_constant<int, ROWS1>{});
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < ROWS1 / 4; ++i) {
+            const int r = 4 * i + rr;
+            f32x4 v = *(const f32x4*)(wave_lds + r * 256 + ((c ^ (r & 15)) << 4));
+            v += rv1[i];
+            *(f32x4*)(obase + (size_t)(64 + 4 * i) * p.ldo) = v;
+        }
+    }
+}
+
+// The two slices of a wave through whichever epilogue applies: the pipelined read-modify-write form for whole slices of the
+// residual epilogues, epilogue_lds otherwise (bf16 outputs, ragged last row panel, run-time switched EPI 0).
+template <int OUT_BF16, int ROWS1, int EPI>
+__device__ __forceinline__ void epilogue_two_slices(const GemmArgs& p, f32x4 (&acc0)[4][4], f32x4 (&acc1)[4][4], char* wave_lds, int row0, int col0, int lane) {
+    if constexpr (!OUT_BF16 && (EPI == 3 || EPI == 4)) {
+        if (row0 + 64 + ROWS1 <= p.M && !(p.debug & 0x800000)) {  // debug bit 23: the old serial read-out (A/B)
+            epilogue_lds_rmw2<ROWS1, EPI>(p, acc0, acc1, wave_lds, row0, col0, lane);
+            return;
+        }
+    }
+    epilogue_lds<OUT_BF16, 64, EPI>(p, acc0, wave_lds, row0, col0, lane);
+    if constexpr (ROWS1 > 0) epilogue_lds<OUT_BF16, ROWS1, EPI>(p, acc1, wave_lds, row0 + 64, col0, lane);
+}
+
+// In-kernel stamps (cdna_hip_programming.md section 7; MI355X_MICROARCH.md "DVFS give-back" item 6).  Diagnostic instantiations
+// only: the shipped kernels execute no stamp.  Row of workgroup b (8 x uint64), written by its first lane into a buffer of its own:
+//   0: blockIdx | HW_ID << 32      1: XCC_ID | LDS_ALLOC << 32      2: s_memtime at entry      3: s_memtime after the K loop
+//   4: s_memtime after the epilogue's last store has completed      5: s_memrealtime (100 MHz) at entry      6: s_memrealtime at the end
+//   7: s_memtime after the prologue (first fragments readable)
+__device__ __forceinline__ unsigned long long gemm_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+struct GemmStamps {
+    unsigned long long t_entry, t_prologue, t_loop, rt_entry;
+    __device__ __forceinline__ void entry() {
+        t_entry = gemm_stamp();
+        rt_entry = __builtin_amdgcn_s_memrealtime();
+    }
+    __device__ __forceinline__ void finish(unsigned long long* buf, int rows) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_end = gemm_stamp(), rt_end = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0 && (int)blockIdx.x < rows) {
+            unsigned hw, xcc, lds;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(lds));
+            unsigned long long* d = buf + (size_t)blockIdx.x * 8;
+            d[0] = (unsigned long long)blockIdx.x | ((unsigned long long)hw << 32);
+            d[1] = (unsigned long long)xcc | ((unsigned long long)lds << 32);
+            d[2] = t_entry, d[3] = t_loop, d[4] = t_end, d[5] = rt_entry, d[6] = rt_end, d[7] = t_prologue;
+        }
+    }
+};
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N >= 0 && N < 64, "vmcnt immediate");
@@ -194,4 +319,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // gemm_bf16_8ph.hip: 256x256 8-phase kernel (N % 256 == 0, K >= 128, 32-bit operand offsets)
 // nf = 16-row fragments per wave (5..8): tile height 32 * nf rows
 // epi: EpiTraits code the host has verified against the argument block (0 = generic)
+// p.stamps != nullptr selects the stamped diagnostic instantiation where one exists (8-phase: nf 6 / 8 with epi 1 / 3; pair: epi 1 / 3)
 int ufm_launch_gemm_8ph(const GemmArgs& p, int out_dtype, hipStream_t stream, int nf = 8, int epi = 0);
+// gemm_bf16_pair.hip: 256x128 4-wave kernel, two resident workgroups per CU (N % 128 == 0, K >= 128, 32-bit operand offsets)
+int ufm_launch_gemm_pair(const GemmArgs& p, int out_dtype, hipStream_t stream, int epi = 0);
