@@ -136,9 +136,9 @@ def test_gemm_8phase_bitwise_equals_128_kernel_repeated(hip, M, N, K):
         for rep in range(3):
             # (1, -128): the 128x128 kernel with the SERIAL read-modify-write read-out of rounds 1-4 (flag 0x800000) -- `want` above comes
             # from round 5's pipelined one (residual loads out of the store chain, gemm_common.h epilogue_lds_rmw2): same bits
-            for variant, rows in ((4, 256), (4, 224), (4, 192), (4, 160), (5, 0), (0, 0), (6, 0), (6, -3), (1, -128), (4, -128), (6, -128)):
+            for variant, rows in ((4, 256), (4, 224), (4, 192), (4, 160), (5, 0), (0, 0), (6, 0), (6, -3), (6, 160), (6, 192), (6, 224), (1, -128), (4, -128), (6, -128)):
                 if variant in (4, 5) and N % 256:
-                    continue
+                    continue  # (6, rows): the pair kernel at the lower tile heights
                 lib.ufm_debug_set_gemm_variant(variant)
                 lib.ufm_debug_set_gemm_tile_rows(max(rows, 0))
                 lib.ufm_debug_set_gemm_flags((-rows) << 16 if rows < 0 else 0)  # (6, -3): second resident workgroups start 3 sleeps late; -128 << 16 = 0x800000

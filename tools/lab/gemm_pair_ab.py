@@ -41,21 +41,23 @@ for _one in (0,):
         def fresh():
             return res0.clone() if mode == "res" else torch.zeros(Mx, N, device="cuda", dtype=torch.bfloat16)
 
-        arms = [("auto", 0, 0)] + [(f"pair s{s}", 6, s << 16) for s in STAG]
+        arms = [("auto", 0, 0, 0)] + [(f"pair s{s}", 6, s << 16, 0) for s in STAG]
+        arms += [(f"pair r{r}", 6, 0, int(r)) for r in os.environ.get("ROWS", "").split(",") if r]
         if os.environ.get("OLD_EPI") and mode == "res":  # the serial read-modify-write read-out of rounds 1-4 (flag 0x800000)
-            arms += [("auto old-epi", 0, 0x800000), ("pair old-epi", 6, 0x800000)]
-        lib.ufm_debug_set_gemm_variant(1); lib.ufm_debug_set_gemm_flags(0)
+            arms += [("auto old-epi", 0, 0x800000, 0), ("pair old-epi", 6, 0x800000, 0)]
+        lib.ufm_debug_set_gemm_variant(1); lib.ufm_debug_set_gemm_flags(0); lib.ufm_debug_set_gemm_tile_rows(0)
         ref = fresh(); run(ref); torch.cuda.synchronize()
         same = {}
-        for name, v, f in arms:
-            lib.ufm_debug_set_gemm_variant(v); lib.ufm_debug_set_gemm_flags(f)
+        for name, v, f, r in arms:
+            lib.ufm_debug_set_gemm_variant(v); lib.ufm_debug_set_gemm_flags(f); lib.ufm_debug_set_gemm_tile_rows(r)
             o = fresh(); run(o); torch.cuda.synchronize()
             same[name] = torch.equal(o.view(torch.uint8), ref.view(torch.uint8))
         scratch = fresh()
         hot = {a[0]: [] for a in arms}; cold = {a[0]: [] for a in arms}
+        arms = [a for a in arms]
         for _ in range(REPS):
-            for name, v, f in arms:
-                lib.ufm_debug_set_gemm_variant(v); lib.ufm_debug_set_gemm_flags(f)
+            for name, v, f, r in arms:
+                lib.ufm_debug_set_gemm_variant(v); lib.ufm_debug_set_gemm_flags(f); lib.ufm_debug_set_gemm_tile_rows(r)
                 run(scratch); torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -69,7 +71,7 @@ for _one in (0,):
                     e0.record(); run(scratch); e1.record(); torch.cuda.synchronize()
                     c.append(e0.elapsed_time(e1) * 1e3)
                 cold[name].append(med(c))
-        lib.ufm_debug_set_gemm_variant(0); lib.ufm_debug_set_gemm_flags(0)
+        lib.ufm_debug_set_gemm_variant(0); lib.ufm_debug_set_gemm_flags(0); lib.ufm_debug_set_gemm_tile_rows(0)
         fl = 2.0 * Mx * N * K
         print(f"M={Mx} N={N} K={K} {mode:4s}: " + " | ".join(
-            f"{n}: hot {med(hot[n]):6.1f} cold {med(cold[n]):6.1f} us ({fl / med(cold[n]) / 1e6:5.0f} TF){'' if same[n] else ' MISMATCH'}" for n, _, _ in arms), flush=True)
+            f"{n}: hot {med(hot[n]):6.1f} cold {med(cold[n]):6.1f} us ({fl / med(cold[n]) / 1e6:5.0f} TF){'' if same[n] else ' MISMATCH'}" for n, _, _, _ in arms), flush=True)

@@ -185,7 +185,7 @@ extern "C" int ufm_debug_set_gemm_stamps(unsigned long long* buf, int rows) {
     return UFM_OK;
 }
 extern "C" int ufm_debug_set_gemm_flags(int flags) {
-    g_gemm_flags = flags & (2 | 4 | 8 | 16 | 32 | 64 | 128 | 0xff00 | 0x7f0000 | 0x800000);  // 0x800000: the serial read-modify-write read-out (A/B of round 5's pipelined one)  // 0x70000: start stagger of the 8-phase kernel's first round (lab)  // 128: never the two-K-tiles-per-barrier form of the 128x128 kernel  // 64: generic (run-time switched) epilogue in the 8-phase kernels  // 16 / 32: lda / ldw = 0 (every tile reads the same rows: an all-L2-hit probe, tools/lab)
+    g_gemm_flags = flags & (2 | 4 | 8 | 16 | 32 | 64 | 128 | 0xff00 | 0x7f0000 | 0x800000 | 0xf000000);  // 0xf000000: flip the four auto rules of the pair kernel (A/B)  // 0x800000: the serial read-modify-write read-out (A/B of round 5's pipelined one)  // 0x70000: start stagger of the 8-phase kernel's first round (lab)  // 128: never the two-K-tiles-per-barrier form of the 128x128 kernel  // 64: generic (run-time switched) epilogue in the 8-phase kernels  // 16 / 32: lda / ldw = 0 (every tile reads the same rows: an all-L2-hit probe, tools/lab)
     return UFM_OK;
 }
 
@@ -279,6 +279,25 @@ extern "C" int ufm_gemm_bf16_rope(const uint16_t* A, int lda, const uint16_t* W,
         nf_lead = g_gemm_tile_rows / 32;
     }
     if ((variant == 4 || variant == 5) && !ok8) variant = 1;
+    // The 256x128 two-resident-workgroups kernel (gemm_bf16_pair.hip) where it measured faster than the choice above, per shape and
+    // row count, isolated launches behind a cold cache (tools/lab/gemm_pair_ab.py, profiles/r05/gemm_pair_ab.log) and in the
+    // two-stream pipeline (profiles/r05/gemm_pair_pipeline_ab.log): the info-sharing widths (D = 768: three or nine 256-column tiles
+    // quantise badly on 256 CUs) and the encoder's QKV at micro-batch row counts.  Flag bits 24..27 flip the four rules (A/B).
+    int nf_pair = g_gemm_tile_rows ? g_gemm_tile_rows / 32 : 8;
+    if (g_gemm_variant == 0 && K >= 128 && fits32 && !g_gemm_tile_rows) {
+        constexpr int PAIR_DEFAULT = 0;
+        const int pol = PAIR_DEFAULT ^ ((g_gemm_flags >> 24) & 15);
+        const bool small = M < 16000;
+        int nfp = 0;
+        if (out_dtype == UFM_BF16) {
+            if ((pol & 1) && K == 768 && (N == 2304 || (N == 3072 && small))) nfp = small ? 7 : 8;
+            if ((pol & 4) && K == 1024 && N == 3072 && small) nfp = 7;
+        } else if (res) {
+            if ((pol & 2) && N == 768 && (K == 768 || !small)) nfp = 6;
+        }
+        if ((pol & 8) && !nfp) nfp = 8;
+        if (nfp) variant = 6, nf_pair = nfp;
+    }
     if (variant == 6 && !(K >= 128 && fits32)) variant = 1;
     auto launch128 = [&](const GemmArgs& q) {
         const int ntm = (q.M - q.m_begin + BM - 1) / BM, ntn128 = N / BN;
@@ -312,7 +331,7 @@ extern "C" int ufm_gemm_bf16_rope(const uint16_t* A, int lda, const uint16_t* W,
     } else if (variant == 4) {
         ufm_launch_gemm_8ph(p, out_dtype, (hipStream_t)stream, nf_lead, epi);
     } else if (variant == 6) {
-        ufm_launch_gemm_pair(p, out_dtype, (hipStream_t)stream, epi);
+        ufm_launch_gemm_pair(p, out_dtype, (hipStream_t)stream, nf_pair, epi);
     } else {
         launch128(p);
     }

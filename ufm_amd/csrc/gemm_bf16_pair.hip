@@ -34,9 +34,12 @@ constexpr int PAIR_LDS = 3 * XH + 3 * WH;  // 72 KiB
 template <int K>
 using IC = std::integral_constant<int, K>;
 
-template <int OUT_BF16, int EPI, bool STAMP = false>
+// NF = 16-row fragments per wave row (5..8): the tile is 32 NF rows high, as in gemm_bf16_8ph.hip (the second 64-row half of a wave's rows
+// has NF - 4 fragments; staging, schedule and every element's accumulation order are those of NF = 8, so all heights are bitwise identical).
+template <int OUT_BF16, int NF, int EPI, bool STAMP = false>
 __device__ __forceinline__ void gemm_bf16_pair_body(const GemmArgs& p, char* smem) {
-    constexpr int BMT = 256, BNT = 128;
+    static_assert(NF >= 5 && NF <= 8, "NF");
+    constexpr int RW = 16 * NF, BMT = 2 * RW, BNT = 128;
     GemmStamps stamps;
     if constexpr (STAMP) stamps.entry();
     const int tid = threadIdx.x, lane = tid & 63;
@@ -72,7 +75,7 @@ __device__ __forceinline__ void gemm_bf16_pair_body(const GemmArgs& p, char* sme
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int lr = (i * 4 + wave) * 8 + srow;                 // local row of the X half-tile, lr & 7 == srow
-            const int brow = (lr >> 6) * 128 + h * 64 + (lr & 63);    // X half h: rows mh = h of both wave rows
+            const int brow = (lr >> 6) * RW + h * 64 + (lr & 63);     // X half h: rows mh = h of both wave rows (rows past RW: unused)
             xsrc[h][i] = 2u * ((unsigned)min(m0 + brow, p.M - 1) * (unsigned)p.lda + chunk);
         }
 #pragma unroll
@@ -113,10 +116,11 @@ __device__ __forceinline__ void gemm_bf16_pair_body(const GemmArgs& p, char* sme
             for (int m = 0; m < 4; ++m) acc[h][n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 xf[4][2], wa[2][2], wb[2][2];
 
-    auto read_x = [&](auto buf) {
+    auto read_x = [&](auto buf, auto mh_) {
         const char* s = smem + decltype(buf)::value * XH + x_base;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            if (decltype(mh_)::value == 1 && i >= NF - 4) continue;
             xf[i][0] = *(const bf16x8*)(s + i * 2048 + ck0);
             xf[i][1] = *(const bf16x8*)(s + i * 2048 + ck1);
         }
@@ -137,7 +141,7 @@ __device__ __forceinline__ void gemm_bf16_pair_body(const GemmArgs& p, char* sme
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < (MH == 0 ? 4 : NF - 4); ++i)
                     acc[MH][NH * 2 + j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][kk], xf[i][kk], acc[MH][NH * 2 + j][i], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -167,13 +171,13 @@ __device__ __forceinline__ void gemm_bf16_pair_body(const GemmArgs& p, char* sme
     // ring slots of tile t: X-lo / W-lo in B2, X-hi / W-hi in B2 + 1 (mod 3); the next tile's lo halves in B2 + 2
     auto tile_body = [&](int t, auto b2_, bf16x8 (&wcur)[2][2], bf16x8 (&wnxt)[2][2]) {  // wcur holds W-lo(t) on entry
         constexpr int B2 = decltype(b2_)::value, B2H = (B2 + 1) % 3, B2N = (B2 + 2) % 3;
-        read_x(IC<B2>{});
+        read_x(IC<B2>{}, IC<0>{});
         l_end(t, IC<0>{}, b2_);
         mma(IC<0>{}, IC<0>{}, wcur);
         read_w(wnxt, IC<B2H>{});
         l_end(t, IC<1>{}, b2_);
         mma(IC<0>{}, IC<1>{}, wnxt);
-        read_x(IC<B2H>{});
+        read_x(IC<B2H>{}, IC<1>{});
         l_end(t, IC<2>{}, b2_);
         mma(IC<1>{}, IC<1>{}, wnxt);
         if (t + 1 < nt) read_w(wnxt, IC<B2N>{});  // W-lo of the next K-tile into the set W-hi(t) just vacated
@@ -229,32 +233,43 @@ __device__ __forceinline__ void gemm_bf16_pair_body(const GemmArgs& p, char* sme
         if (keep == 123.456f) ((float*)p.out)[0] = keep;
         return;
     }
-    epilogue_two_slices<OUT_BF16, 64, EPI>(p, acc[0], acc[1], smem + wave * 16384, m0 + wr * 128, n0 + wc * 64, lane);
+    epilogue_two_slices<OUT_BF16, RW - 64, EPI>(p, acc[0], acc[1], smem + wave * 16384, m0 + wr * RW, n0 + wc * 64, lane);
     if constexpr (STAMP) stamps.finish(p.stamps, p.stamp_rows);
 }
 
-template <int OUT_BF16, int EPI, bool STAMP = false>
+template <int OUT_BF16, int NF, int EPI, bool STAMP = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_pair_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[PAIR_LDS];
-    gemm_bf16_pair_body<OUT_BF16, EPI, STAMP>(p, smem);
+    gemm_bf16_pair_body<OUT_BF16, NF, EPI, STAMP>(p, smem);
 }
 
 }  // namespace
 
-int ufm_launch_gemm_pair(const GemmArgs& p, int out_dtype, hipStream_t stream, int epi) {
-    const int ntm = (p.M - p.m_begin + 255) / 256, ntn = p.N / 128;
+int ufm_launch_gemm_pair(const GemmArgs& p, int out_dtype, hipStream_t stream, int nf, int epi) {
+    const int bmt = 32 * nf;
+    const int ntm = (p.M - p.m_begin + bmt - 1) / bmt, ntn = p.N / 128;
     dim3 grid(ntm * ntn), block(256);
-    if (p.stamps && ((out_dtype == UFM_BF16 && epi == 1) || (out_dtype == UFM_F32 && epi == 3))) {  // diagnostic build
-        if (epi == 1) hipLaunchKernelGGL((gemm_bf16_pair_kernel<1, 1, true>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((gemm_bf16_pair_kernel<0, 3, true>), grid, block, 0, stream, p);
+    if (p.stamps && (nf == 6 || nf == 8) && ((out_dtype == UFM_BF16 && epi == 1) || (out_dtype == UFM_F32 && epi == 3))) {  // diagnostic build
+        if (nf == 6 && epi == 1) hipLaunchKernelGGL((gemm_bf16_pair_kernel<1, 6, 1, true>), grid, block, 0, stream, p);
+        else if (nf == 6) hipLaunchKernelGGL((gemm_bf16_pair_kernel<0, 6, 3, true>), grid, block, 0, stream, p);
+        else if (epi == 1) hipLaunchKernelGGL((gemm_bf16_pair_kernel<1, 8, 1, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((gemm_bf16_pair_kernel<0, 8, 3, true>), grid, block, 0, stream, p);
         return 0;
     }
-#define UFM_LP(OUT_, EPI_) hipLaunchKernelGGL((gemm_bf16_pair_kernel<OUT_, EPI_>), grid, block, 0, stream, p)
-    if (out_dtype == UFM_BF16) {
-        if (epi == 1) UFM_LP(1, 1); else if (epi == 2) UFM_LP(1, 2); else UFM_LP(1, 0);
-    } else {
-        if (epi == 3) UFM_LP(0, 3); else if (epi == 4) UFM_LP(0, 4); else UFM_LP(0, 0);
+#define UFM_LPE(NF_, OUT_, EPI_) hipLaunchKernelGGL((gemm_bf16_pair_kernel<OUT_, NF_, EPI_>), grid, block, 0, stream, p)
+#define UFM_LP(NF_)                                                                                   \
+    case NF_:                                                                                         \
+        if (out_dtype == UFM_BF16) {                                                                  \
+            if (epi == 1) UFM_LPE(NF_, 1, 1); else if (epi == 2) UFM_LPE(NF_, 1, 2); else UFM_LPE(NF_, 1, 0); \
+        } else {                                                                                      \
+            if (epi == 3) UFM_LPE(NF_, 0, 3); else if (epi == 4) UFM_LPE(NF_, 0, 4); else UFM_LPE(NF_, 0, 0); \
+        }                                                                                             \
+        break;
+    switch (nf) {
+        UFM_LP(5) UFM_LP(6) UFM_LP(7) UFM_LP(8)
+        default: return 1;
     }
 #undef UFM_LP
+#undef UFM_LPE
     return 0;
 }
