@@ -25,6 +25,10 @@ Rank 0 prints ONE JSON line.  Extra objects:
                 1e-3 px gate): pairs/s, ms/step and its flow max-abs vs the oracle (rank 0, N=1 only).
   latency_b1_ms single-pair p50 latency (BASELINE metric "pairs/s + p50 latency"): eager launches and
                 HIP-graph replay (ufm_amd.GraphedPredictor).
+  config4 / config5   BASELINE.json's other single-GPU configurations under the same clock (side legs, rank 0, N=1): UFM-Refine
+                518^2 batch 8 and UFM-Base 1036^2 batch 2 -- pairs/s, ms/step, per-family MFMA fractions (attention at N = 10 954).
+  roofline.clock_ghz / frac_at_clock   the clock the chip holds under the dominant family (s_memtime / s_memrealtime stamps of the
+                diagnostic GEMM instantiations after 2 s of load) and `achieved` against the peak AT that clock.
 """
 
 import argparse
@@ -109,11 +113,11 @@ def order_line(line: dict, pairs_per_step: int) -> dict:
         if ps:
             summary["gemm_shape_frac"] = {t.replace(" (read-modify-write)", "").replace(" out", ""): r["frac"] for t, r in ps.items() if r["launches"] > 1}
     for k, v in line.items():
-        if k not in out and k not in ("kernels", "precise_mode", "roofline", "attention", "check_vs_oracle", "latency_b1_ms", "parity_mode", "end_to_end", "attention_share"):
+        if k not in out and k not in ("kernels", "precise_mode", "roofline", "attention", "check_vs_oracle", "latency_b1_ms", "parity_mode", "end_to_end", "attention_share", "config4", "config5"):
             out[k] = v
     if pm is not None:
         out["precise_mode"] = pm
-    for k in ("parity_mode", "check_vs_oracle", "latency_b1_ms", "attention", "end_to_end", "attention_share", "roofline"):
+    for k in ("config4", "config5", "parity_mode", "check_vs_oracle", "latency_b1_ms", "attention", "end_to_end", "attention_share", "roofline"):
         if k in line:
             out[k] = line[k]
     # compact repeat of the judged scalars, last
@@ -135,6 +139,14 @@ def order_line(line: dict, pairs_per_step: int) -> dict:
         summary["latency_b1_ms"] = {k: round(v, 3) for k, v in line["latency_b1_ms"].items() if k.endswith("p50")}
     if "cpu_baseline" in line:
         summary["cpu_pairs_per_s"] = round(line["cpu_baseline"]["value"], 4)
+    if "roofline" in line and "clock_ghz" in line["roofline"]:
+        summary["clock_ghz"] = round(line["roofline"]["clock_ghz"], 3)
+        summary["roofline_frac_at_clock"] = round(line["roofline"]["frac_at_clock"], 4)
+    for k in ("config4", "config5"):
+        if k in line:
+            c = line[k]
+            summary[k] = {"pairs_per_s": round(c["value"], 2), "ms_per_step": round(c["ms_per_step"], 2),
+                          "attention_frac": next((v["frac"] for n, v in c["mfma_families"].items() if n.startswith("attention")), None)}
     for k in ("gather_check", "per_rank_ms_per_step", "gather_wait_ms"):
         if k in line:
             summary[k] = line[k]
@@ -169,6 +181,86 @@ def csrc_sha256() -> str:
     return h.hexdigest()
 
 
+def side_config(ufm_amd, hip, which: str, res: int, batch: int, steps: int, micro_batches: int) -> dict:
+    """One of BASELINE.json's other single-GPU configurations, timed like the headline step (inputs resident, synthetic uint8 pairs,
+    random-init weights): config 4 = UFM-Refine (UniFlowMatchClassificationRefinement, /root/reference/uniflowmatch/models/ufm.py:843-1009)
+    at 518^2, batch 8; config 5 = UFM-Base at 1036^2 (5477-token encoder / 10 954-token joint attention), batch 2."""
+    from ufm_amd.modules import init_weights_
+
+    if which == "refine":
+        m = ufm_amd.UniFlowMatchClassificationRefinement(**ufm_amd.ufm_refine_config(resolution_wh=(res, res))).eval()
+    else:
+        m = ufm_amd.UniFlowMatchConfidence(**ufm_amd.ufm_base_config(resolution_wh=(res, res))).eval()
+    init_weights_(m, seed=0)
+    m = m.to("cuda").set_numerics("fast")
+    m.engine().micro_batches = micro_batches
+    g = torch.Generator().manual_seed(4321)
+    s = torch.randint(0, 256, (batch, res, res, 3), dtype=torch.uint8, generator=g).cuda()
+    t = torch.randint(0, 256, (batch, res, res, 3), dtype=torch.uint8, generator=g).cuda()
+    for _ in range(2):
+        m.predict_correspondences_batched(s, t)
+    torch.cuda.synchronize()
+    c0 = time.perf_counter()
+    for _ in range(steps):
+        m.predict_correspondences_batched(s, t)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - c0) / steps
+    out = {"workload": ("UFM-Refine" if which == "refine" else "UFM-Base") + f", random init, batch={batch} {res}x{res} synthetic pairs, 1xMI355X",
+           "value": batch / dt, "unit": "pairs/s", "ms_per_step": 1e3 * dt, "steps": steps, "numerics": "fast"}
+    hip.TIMER = hip.KernelTimer()
+    m.predict_correspondences_batched(s, t)
+    summ = hip.TIMER.summary()
+    hip.TIMER = None
+    fam = {}
+    for name, d in summ.items():
+        if name in MFMA_PEAKS:
+            work = sum(meta_work(x) for x in d["metas"])
+            fam[name.replace("ufm_", "")] = {"ms": round(d["ms"], 3), "frac": round(work / (d["ms"] * 1e-3) / 1e12 / MFMA_PEAKS[name], 4)}
+    out["mfma_families"] = fam
+    del m
+    torch.cuda.empty_cache()
+    return out
+
+
+def gemm_clock_under_load(hip) -> dict:
+    """MI355X_MICROARCH.md, "DVFS give-back" item 6: the clock the chip holds under the dominant kernel family = delta s_memtime /
+    delta s_memrealtime (100 MHz) stamped around whole workgroups of the diagnostic GEMM instantiations (the shipped kernels execute no
+    stamp; the stamps go to a buffer no kernel reads), after >= 2 s of back-to-back launches of the encoder block's four GEMMs on random data."""
+    M = 21920
+    shapes = ((3072, 1024, "bf16"), (1024, 1024, "res"), (4096, 1024, "gelu"), (1024, 4096, "res"))
+    ops = []
+    for N, K, mode in shapes:
+        A = torch.randn(M, K, device="cuda").bfloat16()
+        W = (torch.randn(N, K, device="cuda") * K**-0.5).bfloat16()
+        bias, gamma = torch.randn(N, device="cuda") * 0.1, 1 + 0.1 * torch.randn(N, device="cuda")
+        out = torch.randn(M, N, device="cuda") if mode == "res" else torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        ops.append((A, W, N, K, out, bias, gamma, mode))
+
+    def block():
+        for A, W, N, K, out, bias, gamma, mode in ops:
+            hip.gemm_bf16(A, W, M, N, K, out, bias=bias, act=hip.ACT_GELU if mode == "gelu" else hip.ACT_NONE, res=out if mode == "res" else None,
+                          gamma=gamma if mode != "gelu" else None)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 2.0:
+        for _ in range(20):
+            block()
+        torch.cuda.synchronize()
+    rows = 4096
+    buf = torch.zeros(rows * 8, device="cuda", dtype=torch.int64)
+    hip._check(hip.lib().ufm_debug_set_gemm_stamps(buf.data_ptr(), rows), "ufm_debug_set_gemm_stamps")
+    try:
+        for _ in range(10):
+            block()
+        torch.cuda.synchronize()
+    finally:
+        hip._check(hip.lib().ufm_debug_set_gemm_stamps(None, 0), "ufm_debug_set_gemm_stamps")
+    d = buf.view(rows, 8).cpu()
+    d = d[d[:, 4] != 0].double()
+    clock = float(((d[:, 4] - d[:, 2]) / (d[:, 6] - d[:, 5]).clamp_min(1.0) * 0.1).median())
+    return {"clock_ghz": clock, "workgroups": int(d.shape[0]),
+            "how": "median over workgroups of delta s_memtime / delta s_memrealtime in the stamped fc1 / proj / fc2 instantiations, after 2 s of the encoder block's four GEMMs back to back (random data)"}
+
+
 def p50_ms(fn, iters: int, warm: int) -> float:
     for _ in range(warm):
         fn()
@@ -195,6 +287,8 @@ def main():
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the extra numerics='parity' timing of the same workload")
     ap.add_argument("--no-precise-mode", action="store_true", help="skip the extra numerics='precise' timing of the same workload")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-pair latency measurement")
+    ap.add_argument("--no-side-configs", action="store_true", help="skip the BASELINE config 4 (UFM-Refine 518^2) and config 5 (UFM-Base 1036^2) side legs")
+    ap.add_argument("--no-clock", action="store_true", help="skip the in-kernel clock measurement of the dominant kernel family")
     ap.add_argument("--gemm-variant", type=int, default=0, help="tuning hook: ufm_debug_set_gemm_variant (0 = auto)")
     ap.add_argument("--attn-variant", type=int, default=0, help="tuning hook: ufm_debug_set_attn_variant (0 = default)")
     ap.add_argument("--concurrent-heads", type=int, default=-1, help="DPT heads on separate streams: -1 = engine default (automatic: only in single-stream forwards), 0 / 1 = force")
@@ -553,6 +647,20 @@ def main():
             pm["covis_max_abs"] = float((gotp.covisibility.mask.cpu() - ref_oracle.covisibility.mask).abs().max())
         line["parity_mode"] = pm
         model.set_numerics("fast")
+
+    # ---- BASELINE configs 4 and 5 under the same clock (side legs, rank 0, N = 1; never part of `value`) ----
+    if rank == 0 and world == 1 and args.numerics == "fast" and not args.no_side_configs and B == 8 and res == 518:
+        del model
+        torch.cuda.empty_cache()
+        line["config4"] = side_config(ufm_amd, hip, "refine", 518, 8, steps=6, micro_batches=args.micro_batches)
+        line["config5"] = side_config(ufm_amd, hip, "base", 1036, 2, steps=4, micro_batches=args.micro_batches)
+
+    # ---- the clock the chip holds under the dominant kernel family (in-kernel stamps, diagnostic instantiations) ----
+    if rank == 0 and world == 1 and args.numerics == "fast" and not args.no_clock and "roofline" in line:
+        clk = gemm_clock_under_load(hip)
+        line["roofline"]["clock_ghz"] = clk["clock_ghz"]
+        line["roofline"]["frac_at_clock"] = line["roofline"]["achieved"] / (line["roofline"]["peak"] * clk["clock_ghz"] / 2.4)
+        line["roofline"]["clock_source"] = clk["how"]
 
     if rank == 0:
         print(json.dumps(order_line(line, B)))

@@ -110,8 +110,13 @@ int ufm_rope2d(void* x, int dtype, int rows, int ld, int col0, int ncols, const 
 /* Two-source attention (cross-attention): softmax(scale * q k^T) v with queries from one buffer and keys / values from
  * another ([U] CrossAttention of the cross-attention info-sharing variant; also self-attention on any column layout).
  *   q: [B*Nq][ldq], k / v: [B*Nk][ldkv], out: [B*Nq][ldo]; head h = columns [64 h, 64 h + 64) of each pointer; Nq != Nk allowed.
- * _bf16: bf16 operands (fast; scale == 0 = q pre-scaled by softmax_scale * log2(e): the persistent LDS-DMA kernel), _f32: exact-fp32 MFMA (parity), _bf16x3: UFM_BF16X2 planes (precise; the lo planes follow at
- * B*Nq*ldq, B*Nk*ldkv and B*Nq*ldo elements). */
+ * _bf16: bf16 operands (fast), _f32: exact-fp32 MFMA (parity), _bf16x3: UFM_BF16X2 planes (precise; the lo planes follow at
+ * B*Nq*ldq, B*Nk*ldkv and B*Nq*ldo elements).
+ * ufm_cross_attention_bf16, contract by `scale` (it forwards to ufm_attention_bf16_strided since round 4):
+ *   scale > 0: the register-staged kernel applies it; ldq / ldkv % 8 == 0, ldo % 4 == 0, q / k / v 16-byte and out 8-byte aligned.
+ *   scale == 0 is NOT an error: it means "q is already multiplied by softmax_scale * log2(e)" (the projection GEMM's epilogue
+ *   does that) and selects the persistent LDS-DMA kernel, which needs ldo % 8 == 0 and a 16-byte aligned out as well.  A caller
+ *   that passes 0 by mistake gets an UNSCALED softmax, not UFM_ERR_ARG.  scale < 0 is rejected. */
 int ufm_cross_attention_bf16(const uint16_t* q, int ldq, const uint16_t* k, const uint16_t* v, int ldkv, uint16_t* out, int ldo,
                              int B, int Nq, int Nk, int H, float scale, void* stream);
 /* The general form of the bf16 kernel: batch item b's queries start at row b * q_batch_rows of q, its keys / values at row
@@ -297,6 +302,12 @@ long long ufm_conv_x3_splitk_ws_bytes(int groups, int B, int H, int W, int Cin, 
  * ufm_gemm_bf16x3: out[M][N] = epilogue(A[M][K] . W[N][K]^T), every product hi*hi + hi*lo + lo*hi, fp32 accumulate.
  *   A: UFM_BF16X2 [2][M][K] (ufm_layernorm / ufm_attention_bf16x3 / a previous ufm_gemm_bf16x3 write it);
  *   W: UFM_BF16X2 [2][N][K], pre-split at pack time.   v = acc + bias[n]; v = act(v) (GELU: branch-free erf, |err| <= 1.5e-7); v *= gamma[n];
+ *   GELU accuracy contract of every split-format epilogue (this entry point, ufm_conv2d_nhwc_bf16x3): ABSOLUTE error <= 4.4e-7
+ *   against the fp64 erf GELU over [-8, 8] (measured, tests/test_kernels_gpu.py::test_split_format_gelu_epilogue_against_fp64_gelu);
+ *   relative error <= 6e-7 for x >= -1 and 5.6e-5 on [-3, -1]; NO relative bound below x = -3 (gelu < 4e-3 there and the
+ *   erfc polynomial bounds the absolute error only) -- an order below the 2^-17 resolution of the split store for the fp32-scale
+ *   values the trunk carries, not a relative-accuracy GELU for tiny outputs (ufm_gemm_bf16's bf16 GELU, gelu_bf16_x4, keeps
+ *   relative accuracy in the negative tail instead).
  *   out_dtype UFM_BF16X2: out = split(v) as [2][M][N];   out_dtype UFM_F32: v += res[m][n] (fp32, may be NULL, may alias
  *   out: the fp32 residual stream is updated in place), out[m][n] = v.
  *   Requirements: K % 32 == 0, N % 32 == 0, 16-byte aligned pointers.  zero_page: >= 128 B of zeros (device).

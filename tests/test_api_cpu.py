@@ -218,3 +218,30 @@ def test_bench_line_keeps_every_judged_scalar_in_its_last_2000_characters():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in back, key
     assert abs(back["end_to_end"]["frac"] - (17023.0 + 5163.0 + 3487.0 + 316.0) * (216.2 / 8) / 1e3 / 2500.0) < 1e-9
+
+
+def test_param_epoch_moves_on_every_kind_of_registration():
+    """the engines' cached Parameter list is re-walked only when engine.PARAM_EPOCH moved.  torch's
+    parameter-registration hook alone misses a swapped-in SUB-MODULE and a new buffer; the module- and buffer-registration hooks
+    (round 5) catch them.  CPU-only: the hooks are plain torch."""
+    import copy
+
+    import torch
+    from ufm_amd import engine
+
+    seq = torch.nn.Sequential(torch.nn.Linear(2, 2), torch.nn.ReLU())
+    e = engine.PARAM_EPOCH[0]
+    seq[0] = copy.deepcopy(seq[0])  # Sequential.__setitem__ -> setattr of a Module: no Parameter is registered anywhere
+    assert engine.PARAM_EPOCH[0] > e
+    e = engine.PARAM_EPOCH[0]
+    seq.extra_head = torch.nn.Linear(2, 2)
+    assert engine.PARAM_EPOCH[0] > e
+    e = engine.PARAM_EPOCH[0]
+    seq.add_module("third", torch.nn.Identity())
+    assert engine.PARAM_EPOCH[0] > e
+    e = engine.PARAM_EPOCH[0]
+    seq.register_buffer("table", torch.zeros(3))
+    assert engine.PARAM_EPOCH[0] > e
+    e = engine.PARAM_EPOCH[0]
+    seq[0].bias = torch.nn.Parameter(torch.zeros(2))
+    assert engine.PARAM_EPOCH[0] > e

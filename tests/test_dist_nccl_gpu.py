@@ -16,7 +16,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_predict_sharded_on_rccl_equals_unsharded():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
-    n = min(torch.cuda.device_count(), 6)  # at most 6 processes may use the card(s) at once on the lease boxes
+    # One rank per visible GPU -- on an 8-GPU node world = 8, so the first world-8 RCCL all_gather is this test and not the benchmark.
+    # The lease boxes allow at most 6 processes on a card at once: with fewer than 8 devices the world is capped at 6 (they have one
+    # GPU, so world = 1 there).  UFM_TEST_NCCL_RANKS overrides either way.
+    ndev = torch.cuda.device_count()
+    n = int(os.environ.get("UFM_TEST_NCCL_RANKS", "0")) or (ndev if ndev >= 8 else min(ndev, 6))
+    assert 1 <= n <= ndev, f"UFM_TEST_NCCL_RANKS={n} but {ndev} device(s) are visible"
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]

@@ -752,6 +752,10 @@ def test_hip_graph_survives_eager_calls_with_other_shapes_and_numerics(env):
     want = prod.predict_correspondences_batched(a, b).flow.flow_output.clone()
     gp = ufm_amd.GraphedPredictor(prod, a, b)
     assert torch.equal(gp(a, b).flow.flow_output, want)
+    # round 5: the private engine shares the eager engine's immutable packed weights (one copy per model and numerics) ...
+    assert gp._engine is not prod.engine()
+    assert gp._engine.pe_w.data_ptr() == prod.engine().pe_w.data_ptr() and gp._engine.enc_blocks is prod.engine().enc_blocks
+    assert gp._engine._bufs is not prod.engine()._bufs  # ... but never its workspace
     big_a, big_b = u8((5, 56, 56, 3), 43).to(DEV), u8((5, 56, 56, 3), 44).to(DEV)
     prod.predict_correspondences_batched(big_a, big_b)          # another batch size: the shared workspace is reallocated
     prod.set_numerics("parity").predict_correspondences_batched(big_a, big_b)  # another engine altogether
@@ -779,6 +783,24 @@ def test_hip_graph_survives_eager_calls_with_other_shapes_and_numerics(env):
     last.bias = torch.nn.Parameter(last.bias.detach().clone())
     with pytest.raises(RuntimeError, match="parameters changed"):
         gp2(a, b)
+    # a whole SUB-MODULE swapped in (round 5, ADVICE): torch's parameter-registration hook does not fire for ``parent[i] = module`` /
+    # ``model.attr = module`` -- the module-registration hook does.  Between two eager forwards the engine must re-pack; between a
+    # capture and a replay the graph must refuse.
+    import copy
+
+    parent = prod.head1[0][1].conv2  # the Sequential that holds the flow head's final 1x1 convolution
+    shifted = copy.deepcopy(parent[2])
+    with torch.no_grad():
+        shifted.bias.add_(2.0)
+    kept = parent[2]
+    gp3 = ufm_amd.GraphedPredictor(prod, a, b)
+    parent[2] = shifted  # Sequential.__setitem__ -> setattr of a Module: no Parameter is registered anywhere
+    moved2 = prod.predict_correspondences_batched(a, b).flow.flow_output
+    assert (moved2 - before).abs().min().item() > 1.5  # the eager engine picked the new module's weights up
+    with pytest.raises(RuntimeError, match="parameters changed"):
+        gp3(a, b)
+    parent[2] = kept
+    assert torch.equal(prod.predict_correspondences_batched(a, b).flow.flow_output, before)
 
 
 def test_hip_graph_capture_with_level_chain_branches_inside_the_two_stream_heads(env):

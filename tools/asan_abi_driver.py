@@ -52,6 +52,15 @@ expect((-1,), lib.ufm_gemm_bf16(P, 64, P, 64, 1 << 30, 1 << 20, 64, None, 0, Non
 expect((-1,), lib.ufm_attention_bf16(None, None, 1, 1, 1, 0.125, None), "attention null")
 expect((-1,), lib.ufm_attention_bf16_strided(P, 64, 16, P, P, 64, 128, P, 64, 64, 1, 64, 128, 1, 0.0, None), "strided batch rows")
 expect((-1,), lib.ufm_attention_bf16_strided(P, 60, 64, P, P, 64, 128, P, 64, 64, 1, 64, 128, 1, 0.0, None), "strided ldq")
+# ufm_cross_attention_bf16 by `scale` (include/ufm_hip.h): scale > 0 keeps the looser output contract (ldo % 4, 8-byte aligned out);
+# scale == 0 (q pre-scaled: the LDS-DMA kernel) needs ldo % 8 and a 16-byte aligned out; scale < 0 is an argument error
+P8 = C.c_void_p(P.value + 8)
+expect((-1,), lib.ufm_cross_attention_bf16(P, 64, P, P, 64, P, 68, 1, 64, 64, 1, 0.0, None), "cross scale=0 ldo % 8")
+expect((-1,), lib.ufm_cross_attention_bf16(P, 64, P, P, 64, P8, 64, 1, 64, 64, 1, 0.0, None), "cross scale=0 out alignment")
+expect((-1,), lib.ufm_cross_attention_bf16(P, 64, P, P, 64, P, 64, 1, 64, 64, 1, -0.125, None), "cross scale<0")
+expect((-1,), lib.ufm_cross_attention_bf16(P, 64, P, P, 64, P, 66, 1, 64, 64, 1, 0.125, None), "cross scale>0 ldo % 4")
+expect((-1,), lib.ufm_debug_set_gemm_stamps(P, 0), "stamps buffer without rows")
+expect((0,), lib.ufm_debug_set_gemm_stamps(None, 0), "stamps off")
 expect((-1,), lib.ufm_gather_rows_f32(P, 62, P, 4, 64, P, 64, None), "gather ld")
 expect((-1,), lib.ufm_debug_set_gemm_variant(3), "variant")
 expect((-1,), lib.ufm_debug_set_gemm_tile_rows(100), "tile rows")
@@ -64,7 +73,7 @@ try:
 except Exception:
     has_gpu = False
 if not has_gpu:
-    for variant in (0, 1, 4, 5):
+    for variant in (0, 1, 4, 5, 6):
         lib.ufm_debug_set_gemm_variant(variant)
         for rows in (0, 160, 192, 224, 256):
             lib.ufm_debug_set_gemm_tile_rows(rows)
@@ -79,5 +88,13 @@ if not has_gpu:
         rc = lib.ufm_conv2d_nhwc_bf16x3(P, B, H, H, Cin, P, Cout, k, k, 1, k // 2, 0, P, 0, None, None, 0, P, None, P, 3, None)
         expect((0, -2), rc, ("conv dispatch", B, H, Cin, Cout, k))
     expect((0, -2), lib.ufm_attention_bf16(P, P, 2, 1370, 16, 0.0, None), "attention launch bookkeeping")
+    expect((0, -2), lib.ufm_cross_attention_bf16(P, 64, P, P, 64, P8, 68, 1, 64, 64, 1, 0.125, None), "cross scale>0: ldo % 4 and an 8-byte aligned out are enough")
+    for flags in (1 << 24, 2 << 24, 4 << 24, 8 << 24):  # the pair kernel's auto rules, flipped on
+        lib.ufm_debug_set_gemm_flags(flags)
+        for M in (2738, 10952, 21920):
+            for N, K, od in ((2304, 768, 1), (768, 768, 0), (768, 3072, 0), (3072, 1024, 1), (3072, 768, 1)):
+                rc = lib.ufm_gemm_bf16(P, K, P, K, M, N, K, P, 0, P, P if not od else None, N, 0, P, od, N, 0, None)
+                expect((0, -2), rc, ("pair rules", flags, M, N, K, od))
+    lib.ufm_debug_set_gemm_flags(0)
     expect((0, -2), lib.ufm_layernorm(P, 1024, None, 100, 1024, P, P, 1e-6, P, 1, 1024, None), "layernorm")
 print(f"asan abi driver ok: {calls} calls, no sanitizer report")

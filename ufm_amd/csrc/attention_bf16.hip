@@ -259,9 +259,12 @@ extern "C" int ufm_attention_bf16_strided(const uint16_t* q, int ldq, int q_batc
                                           uint16_t* out, int ldo, int out_batch_rows, int B, int Nq, int Nk, int H, float scale, void* stream) {
     UFM_REQUIRE(q && k && v && out, "ufm_attention_bf16_strided: null pointer");
     UFM_REQUIRE(B > 0 && Nq > 0 && Nk > 0 && H > 0 && scale >= 0.0f && (int64_t)((Nq + QB - 1) / QB) * H * B < (1ll << 31), "ufm_attention_bf16_strided: bad shape B=%d Nq=%d Nk=%d H=%d", B, Nq, Nk, H);
-    UFM_REQUIRE(ldq >= H * 64 && ldkv >= H * 64 && ldo >= H * 64 && ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 8 == 0, "ufm_attention_bf16_strided: bad leading dimensions %d/%d/%d", ldq, ldkv, ldo);
+    // the scale > 0 kernel (unchanged since round 1) stores 8-byte pieces: it keeps its original, looser output contract (ldo % 4, 8-byte
+    // aligned out); the LDS-DMA kernel of the scale == 0 form stores whole 16-byte chunks
+    const int ldo_mult = scale == 0.0f ? 8 : 4, out_align = scale == 0.0f ? 16 : 8;
+    UFM_REQUIRE(ldq >= H * 64 && ldkv >= H * 64 && ldo >= H * 64 && ldq % 8 == 0 && ldkv % 8 == 0 && ldo % ldo_mult == 0, "ufm_attention_bf16_strided: bad leading dimensions %d/%d/%d", ldq, ldkv, ldo);
     UFM_REQUIRE(q_batch_rows >= Nq && kv_batch_rows >= Nk && out_batch_rows >= Nq, "ufm_attention_bf16_strided: batch strides %d/%d/%d rows are shorter than Nq=%d / Nk=%d", q_batch_rows, kv_batch_rows, out_batch_rows, Nq, Nk);
-    UFM_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 && ((uintptr_t)out % 16) == 0, "ufm_attention_bf16_strided: misaligned pointer");
+    UFM_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 && ((uintptr_t)out % out_align) == 0, "ufm_attention_bf16_strided: misaligned pointer");
     UFM_REQUIRE((int64_t)kv_batch_rows * ldkv * 2 < (1ll << 31), "ufm_attention_bf16_strided: one batch item's K/V rows exceed the 32-bit DMA offset");
     if (scale == 0.0f) {
         ufm_launch_attn_pw2(q, ldq, q_batch_rows, k, v, ldkv, kv_batch_rows, out, ldo, out_batch_rows, B, Nq, Nk, H, g_attn_debug, (hipStream_t)stream);

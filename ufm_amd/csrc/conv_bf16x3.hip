@@ -399,7 +399,8 @@ extern "C" int ufm_conv2d_nhwc_bf16x3_grouped(const uint16_t* in, int groups, in
         if (S > 1) {
             const long long need = conv_x3_splitk_bytes(M * groups, Cout, S);
             UFM_REQUIRE(((uintptr_t)splitk_ws % 16) == 0 && splitk_ws_bytes >= need, "ufm_conv2d_nhwc_bf16x3: split-K workspace of %lld bytes, this layer needs %lld (ufm_conv_x3_splitk_ws_bytes)", splitk_ws_bytes, need);
-            UFM_REQUIRE(((M + 63) / 64 + groups) * (long long)((Cout + 63) / 64) <= SPLITK_COUNTER_BYTES / 4, "ufm_conv2d_nhwc_bf16x3: too many tiles for the split-K counters");
+            // one counter per tile of ANY shape the launcher may pick: the smallest is 64 rows x 32 columns, rows are tiled per group
+            UFM_REQUIRE(((M + 63) / 64) * (long long)groups * ((Cout + 31) / 32) <= SPLITK_COUNTER_BYTES / 4, "ufm_conv2d_nhwc_bf16x3: too many tiles for the split-K counters");
             p.splitk = S;
             p.counters = (unsigned*)splitk_ws;
             p.slab = (float*)((char*)splitk_ws + SPLITK_COUNTER_BYTES);

@@ -27,6 +27,7 @@ Numerics modes
 from __future__ import annotations
 
 import threading
+import weakref
 from typing import Any, Dict, List, Optional, Tuple
 
 import torch
@@ -73,7 +74,13 @@ def _on_parameter_registration(module, name, param):  # noqa: ARG001
     PARAM_EPOCH[0] += 1
 
 
+# The parameter hook alone misses a whole SUB-MODULE swapped in (``model.head1 = other_head``, ``seq[i] = copy.deepcopy(mod)``,
+# ``add_module``): torch fires the module-registration hook for those, and the buffer hook for ``register_buffer`` / buffer assignment.
+# (``del m.bias`` and direct writes to ``m._parameters[...]`` fire no hook at all: like edits through ``p.data`` they are invisible to
+# any guard short of walking the tree on every call.)
 torch.nn.modules.module.register_module_parameter_registration_hook(_on_parameter_registration)
+torch.nn.modules.module.register_module_module_registration_hook(_on_parameter_registration)
+torch.nn.modules.module.register_module_buffer_registration_hook(_on_parameter_registration)
 
 
 class _Blk:
@@ -276,6 +283,11 @@ class _MoGeHead:
         self.shift = [s for a in self.adaptors for s in a.shift]
 
 
+# model -> {numerics: (pack key, {Engine attribute: packed weights})}: one packed copy per (model, numerics), shared by its engines
+_PACK_CACHE: "weakref.WeakKeyDictionary[nn.Module, Dict[str, Any]]" = weakref.WeakKeyDictionary()
+_PER_ENGINE_STATE = frozenset(("_bufs", "_tables", "_packed_key", "_plist", "_plist_epoch", "_tls", "_streams", "_head_streams", "_level_streams", "_head_group"))
+
+
 class Engine:
     def __init__(self, model: nn.Module, numerics: str = "fast"):
         if numerics not in ("fast", "precise", "parity", "parity_x3heads"):
@@ -335,6 +347,7 @@ class Engine:
         self.level_streams = False
         self.level_streams_max_images = 2
         self._level_streams: Dict[Any, List[torch.cuda.Stream]] = {}
+        self._init_names = frozenset(self.__dict__) | {"_init_names"}  # everything _pack adds on top is packed weights / their metadata
 
     # ------------------------------------------------------------------ packing
     def _pack(self) -> None:
@@ -357,6 +370,16 @@ class Engine:
         self.dev = dev
         self._tables.clear()
         self._bufs.clear()
+        # The packed weights are immutable once built: every Engine of this model with the same (device, numerics, parameter
+        # versions / storage) -- the eager engine and the private engine of each GraphedPredictor -- shares ONE copy (round 5; each
+        # used to pack its own 0.85 GB).  Workspace, tables and streams stay per engine.  A graph captured on a shared pack keeps the
+        # tensors alive through its engine's references even after the model's weights change and the cache entry is replaced.
+        cached = _PACK_CACHE.setdefault(m, {}).get(self.numerics)
+        if cached is not None and cached[0] == key:
+            self.__dict__.update(cached[1])
+            self._head_group = None
+            self._packed_key = key
+            return
         enc = m.encoder.model
         self.P = enc.patch_size
         self.D = enc.embed_dim
@@ -437,6 +460,8 @@ class Engine:
             if d % 32 != 0:
                 raise NotImplementedError(f"{what}={d} must be a multiple of 32")
         self._packed_key = key
+        packed = {k: v for k, v in self.__dict__.items() if k not in _PER_ENGINE_STATE and k not in self._init_names}  # what _pack set
+        _PACK_CACHE[m][self.numerics] = (key, packed)
 
     # ------------------------------------------------------------------ small helpers
     def buf(self, name: str, shape: Tuple[int, ...], dtype=torch.float32) -> torch.Tensor:
@@ -757,6 +782,14 @@ class Engine:
         # its level is read.  Bit-identical (same kernels on the same buffers).
         cur = torch.cuda.current_stream(self.dev)
         use_ls = self.level_streams and Bt <= self.level_streams_max_images and hip.TIMER is None
+        if use_ls and fork_from is None and torch.cuda.is_current_stream_capturing():
+            # Under hipGraph capture a fork from an ALREADY FORKED stream segfaults inside hipStreamEndCapture (ROCm 7.0 / 7.2 runtime,
+            # profiles/r04/capture_nested_fork.log).  If this call runs on one of the engine's own forked streams (a head stream, a
+            # micro-batch stream) and the caller did not say where that stream was forked from, the level chains stay serial
+            # (same kernels, same buffers, same bits) instead of taking the process down.
+            forked = [st for sl in self._head_streams.values() for st in sl] + list(self._streams)
+            if any(cur == st for st in forked):
+                use_ls = False
         r: List[Any] = [None] * 4
         lst: List[torch.cuda.Stream] = []
         if use_ls:

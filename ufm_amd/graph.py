@@ -9,7 +9,9 @@ those of the eager call (same kernels, same order, same workspace; tests/test_mo
 
 The captured graph holds raw pointers into the workspace and the packed weights of the Engine it was captured on.  That
 Engine is PRIVATE to the GraphedPredictor: eager calls on the same model (another batch size or resolution reallocates the
-shared engine's workspace, ``set_numerics`` drops it) never touch the graph's buffers.  What a replay cannot follow is a
+shared engine's workspace, ``set_numerics`` drops it) never touch the graph's buffers.  The packed weights themselves are
+immutable and shared between all engines of a model (``engine._PACK_CACHE``: one copy per model and numerics; the private
+engine keeps them alive for as long as the graph exists).  What a replay cannot follow is a
 change of the model's parameters: ``__call__`` compares the parameters' versions and storage with those at capture time and
 raises instead of replaying stale weights.
 
@@ -35,7 +37,7 @@ class GraphedPredictor:
         from .engine import Engine
 
         shared = model._engine
-        eng = self._engine = Engine(model, model.numerics)  # private workspace + packed weights: nothing else ever runs on it
+        eng = self._engine = Engine(model, model.numerics)  # private workspace: nothing else ever runs on it (packed weights: shared, immutable)
         if shared is not None:
             eng.concurrent_heads, eng.fused_tail = shared.concurrent_heads, shared.fused_tail
             eng.group_heads, eng.last_layer_view1, eng.conv_splitk = shared.group_heads, shared.last_layer_view1, shared.conv_splitk
