@@ -131,3 +131,33 @@ def test_host_side_of_the_abi_under_asan_and_ubsan():
 
     r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "asan_abi_driver.py")], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "asan abi driver ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_split_precision_attention_isa_audit_runs_in_the_build_and_catches_a_compiler_dma_wait(tmp_path):
+    """attention_bf16x3_pw.hip (round 5) issues its LDS-DMAs from inline asm (M0 written in the statement that uses it) and orders them
+    with its own vmcnt(0) + s_barrier; tools/check_attn_x3_isa.py, run by the Makefile, fails the build when hipcc uses M0 itself,
+    emits an LDS-DMA of its own, or puts a vmcnt wait inside one of the loop's MFMA blocks (what the LDS-DMA builtin caused: a wait
+    for the tile just requested, every tile).  The audit passes on the built assembly and fails on two doctored copies."""
+    import os
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "ufm_amd", "csrc")
+    assert "check_attn_x3_isa.py" in open(os.path.join(csrc, "Makefile")).read()
+    subprocess.run(["make", "-C", csrc, "build/attention_bf16x3_pw.o"], check=True, capture_output=True)
+    asm = os.path.join(csrc, "build", "attention_bf16x3_pw-hip-amdgcn-amd-amdhsa-gfx950.s")
+    tool = os.path.join(root, "tools", "check_attn_x3_isa.py")
+    ok = subprocess.run([sys.executable, tool, asm], capture_output=True, text=True)
+    assert ok.returncode == 0 and "no vmcnt wait inside an MFMA block" in ok.stdout, ok.stdout
+    txt = open(asm).read()
+    mf = [m.start() for m in re.finditer(r"^\s*v_mfma_f32_32x32x16_bf16", txt, re.M)]
+    assert len(mf) >= 96
+    doctored = [txt[: mf[60]] + "\ts_waitcnt vmcnt(0)\n" + txt[mf[60]:],     # a compiler-style wait between two MFMAs of a block
+                txt.replace("#ASMSTART", "#asmstart")]                          # the asm DMAs read as compiler-generated code
+    for i, t in enumerate(doctored):
+        bad = tmp_path / f"bad_x3_{i}.s"
+        bad.write_text(t)
+        r = subprocess.run([sys.executable, tool, str(bad)], capture_output=True, text=True)
+        assert r.returncode != 0, (i, r.stdout[-400:])

@@ -1040,6 +1040,30 @@ def test_attention_bf16x3(hip, B, N, H):
     assert err <= 1e-4, err
 
 
+@pytest.mark.parametrize("B,N,H", [(2, 1370, 2), (1, 2738, 1), (3, 200, 2), (1, 64, 1), (1, 37, 1), (2, 129, 3), (1, 64 * 5 + 1, 2)])
+def test_attention_bf16x3_round5_kernel_is_bitwise_the_round1_kernel(hip, B, N, H):
+    """attention_bf16x3_pw.hip (round 5: LDS-DMA rings, QK^T of tile t + 1 interleaved with the softmax of tile t) performs, per
+    accumulator, exactly the MFMA sequence and the softmax operations of attention_bf16x3.hip in its order: the outputs must agree
+    BIT FOR BIT -- repeated launches (a DMA that lands late, or a ring stage re-filled early, shows as a rare wrong tile), one tile
+    only (N <= 64), odd tile counts, a ragged last key tile, a ragged last query block; with moving maxima (large scores)."""
+    lib = hip.lib()
+    qkv = rnd(B * N, 3 * H * 64, seed=N, scale=1.5)
+    qkv[N // 2, H * 64 : H * 64 + 64] = qkv[N // 3, 0:64] * 9.0  # one key aligned with one query: a late, large maximum move
+    qs = split(qkv).to(DEV)
+    try:
+        lib.ufm_debug_set_attn_variant(2)  # the round-1 kernel
+        want = torch.full((2, B * N, H * 64), 7.0, device=DEV, dtype=torch.bfloat16)
+        hip.attention_x3(qs, want, B, N, H, 0.125)
+        for variant in (0, 4):  # four waves per workgroup (shipped), eight (A/B)
+            lib.ufm_debug_set_attn_variant(variant)
+            for rep in range(4):
+                got = torch.full((2, B * N, H * 64), 3.0, device=DEV, dtype=torch.bfloat16)
+                hip.attention_x3(qs, got, B, N, H, 0.125)
+                assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (variant, rep)
+    finally:
+        lib.ufm_debug_set_attn_variant(0)
+
+
 def test_attention_bf16x3_spike_moves_the_running_maximum(hip):
     """One key per 64-key tile with a growing score: every tile moves the running maximum (the rescale branch), then a long
     flat stretch where it never moves (the skipped-rescale branch); checked against the fp64 statement on every row."""

@@ -243,6 +243,12 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(const uint16_t* __restr
 
 }  // namespace
 
+// attention_bf16x3_pw.hip: the round-5 kernel (one wave per SIMD, two q-blocks per wave, LDS-DMA rings); bitwise this file's kernel
+int ufm_launch_attn_x3_pw(const uint16_t* q, int ldq, long long q_plane, const uint16_t* k, const uint16_t* v, int ldkv, long long in_plane,
+                          uint16_t* out, int ldo, long long out_plane, int B, int Nq, int Nk, int H, float c, hipStream_t stream, int waves);
+int ufm_attn_x3_use_old();  // attention_bf16.hip: ufm_debug_set_attn_variant bit 1
+int ufm_attn_x3_waves();    // bit 2: eight waves per workgroup instead of four
+
 extern "C" int ufm_attention_bf16x3(const uint16_t* qkv, uint16_t* out, int B, int N, int H, float scale, void* stream) {
     UFM_REQUIRE(qkv && out, "ufm_attention_bf16x3: null pointer");
     UFM_REQUIRE(B > 0 && N > 0 && H > 0 && (int64_t)((N + QB - 1) / QB) * H * B < (1ll << 31), "ufm_attention_bf16x3: bad shape B=%d N=%d H=%d", B, N, H);
@@ -250,6 +256,12 @@ extern "C" int ufm_attention_bf16x3(const uint16_t* qkv, uint16_t* out, int B, i
     UFM_REQUIRE(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 8) == 0, "ufm_attention_bf16x3: misaligned pointer");
     const long long rows = (long long)B * N;
     dim3 grid(((N + QB - 1) / QB) * H * B), block(256);
+    // the LDS-DMA kernel addresses one batch item's K / V rows with 32-bit byte offsets and stages 16-byte chunks
+    const bool pw_ok = !ufm_attn_x3_use_old() && (long long)N * 3 * H * 64 * 2 < (1ll << 31);
+    if (pw_ok)
+        ufm_launch_attn_x3_pw(qkv, 3 * H * 64, rows * 3 * H * 64, qkv + H * 64, qkv + 2 * H * 64, 3 * H * 64, rows * 3 * H * 64, out, H * 64, rows * H * 64, B, N, N, H,
+                              scale * 1.44269504088896340736f, (hipStream_t)stream, ufm_attn_x3_waves());
+    else
     hipLaunchKernelGGL(attn_x3_kernel, grid, block, 0, (hipStream_t)stream, qkv, 3 * H * 64, rows * 3 * H * 64, qkv + H * 64, qkv + 2 * H * 64, 3 * H * 64,
                        rows * 3 * H * 64, out, H * 64, rows * H * 64, N, N, H, scale * 1.44269504088896340736f);
     UFM_CHECK_LAUNCH("ufm_attention_bf16x3");
@@ -263,6 +275,10 @@ extern "C" int ufm_cross_attention_bf16x3(const uint16_t* q, int ldq, const uint
     UFM_REQUIRE(ldq >= H * 64 && ldkv >= H * 64 && ldo >= H * 64 && ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 4 == 0, "ufm_cross_attention_bf16x3: bad leading dimensions %d/%d/%d", ldq, ldkv, ldo);
     UFM_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 && ((uintptr_t)out % 8) == 0, "ufm_cross_attention_bf16x3: misaligned pointer");
     dim3 grid(((Nq + QB - 1) / QB) * H * B), block(256);
+    if (!ufm_attn_x3_use_old() && (long long)Nk * ldkv * 2 < (1ll << 31))
+        ufm_launch_attn_x3_pw(q, ldq, (long long)B * Nq * ldq, k, v, ldkv, (long long)B * Nk * ldkv, out, ldo, (long long)B * Nq * ldo, B, Nq, Nk, H,
+                              scale * 1.44269504088896340736f, (hipStream_t)stream, ufm_attn_x3_waves());
+    else
     hipLaunchKernelGGL(attn_x3_kernel, grid, block, 0, (hipStream_t)stream, q, ldq, (long long)B * Nq * ldq, k, v, ldkv, (long long)B * Nk * ldkv, out, ldo,
                        (long long)B * Nq * ldo, Nq, Nk, H, scale * 1.44269504088896340736f);
     UFM_CHECK_LAUNCH("ufm_cross_attention_bf16x3");
