@@ -161,7 +161,9 @@ int ufm_debug_set_attn_variant(int v);
  * 3 = 128-row kernels only and never the deep (4-stage) ring; + 16 = the serial per-pass residual read-out of rounds 1-4 in the
  * epilogue instead of round 5's grouped loads (bitwise the same results; A/B). */
 int ufm_debug_set_conv_variant(int v);
-/* Tuning hook for ufm_upsample_bilinear_nhwc (split format): 1 = LDS-tiled kernel where applicable (default), 0 = never. */
+/* Tuning hook, bit mask (default 1): bit 0 -- ufm_upsample_bilinear_nhwc (split format) on the LDS-tiled kernel where applicable;
+ * bit 1 -- ufm_dpt_tail_fused with the plain stage-A tile of rounds 1-4 (2-way LDS bank conflicts in stage B) instead of round 5's
+ * half-swapped one (bitwise the same results; A/B). */
 int ufm_debug_set_upsample_variant(int tiled);
 
 /* `ufm infer` post-processing: warp the target image into the source frame with the predicted

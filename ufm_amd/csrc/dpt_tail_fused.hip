@@ -23,6 +23,8 @@
 // the sequential fp32 dot of ufm_head_tail, the adaptor), so fused and unfused outputs are BIT-IDENTICAL (tested).
 #include "common.h"
 
+int ufm_upsample_variant_flags();  // pointwise.hip: ufm_debug_set_upsample_variant
+
 namespace {
 
 constexpr int TS = 16, HS = TS + 2, NPX = HS * HS;  // 16 x 16 tile, 18 x 18 halo
@@ -45,6 +47,7 @@ struct TailFusedArgs {
     long long in_plane, w_plane;
     int B, h, w, H, W, Ct;
     float sy, sx;
+    int t_swap;  // 4: the bank-conflict-free T image (default); 0: the plain image of rounds 1-4 (A/B: ufm_debug_set_upsample_variant bit 1)
     int kind[8];
     float a[8], d[8];
 };
@@ -158,9 +161,14 @@ __global__ __launch_bounds__(256, 2) void dpt_tail_fused_kernel(TailFusedArgs p)
                 t0[j] = lx0 * v0[j] + lx1 * v1[j];
                 t1[j] = lx0 * v0[4 + j] + lx1 * v1[4 + j];
             }
+            // T entry e = (r, hx) is 128 B = half the LDS's bank row: entries e and e + 2 start on the same bank.  Stage B's
+            // ds_read_b128 lane groups take four consecutive entries (four lanes x 16 B at a 32-B stride each), so e / e + 2 met on the
+            // same banks: the 2-way conflicts PMC counted (30 M cycles per launch, rounds 2-4).  The two 16-byte halves of every 32-B
+            // pair are swapped in entries with bit 1 set: e + 2's lanes then fill the holes e's lanes leave.  Same values, same bits.
             float* dst = T + a_dst[k];
-            *(f32x4*)dst = t0;
-            *(f32x4*)(dst + 4) = t1;
+            const int tsw = ((a_dst[k] >> 6) & 1) ? p.t_swap : 0;  // (entry >> 1) & 1 -> 4 floats
+            *(f32x4*)(dst + tsw) = t0;
+            *(f32x4*)(dst + (4 ^ tsw)) = t1;
         }
         // this pass's weights: requested now, parked in LDS after stage B (their latency runs under stage B, which only
         // touches LDS); not earlier, so that they are never live beside the 64 registers of stage-A loads
@@ -178,9 +186,11 @@ __global__ __launch_bounds__(256, 2) void dpt_tail_fused_kernel(TailFusedArgs p)
                 const int y0 = (int)fy;
                 const int y1 = y0 + (y0 < p.h - 1 ? 1 : 0);
                 const float ly1 = fy - y0, ly0 = 1.f - ly1;
-                const float* a = T + ((y0 - ybase) * HS + hx) * 32 + c8 * 8;
-                const float* c = T + ((y1 - ybase) * HS + hx) * 32 + c8 * 8;
-                const f32x4 a0 = *(const f32x4*)a, a1 = *(const f32x4*)(a + 4), c0 = *(const f32x4*)c, c1 = *(const f32x4*)(c + 4);
+                const int ea = (y0 - ybase) * HS + hx, ec = (y1 - ybase) * HS + hx;
+                const float* a = T + ea * 32 + c8 * 8;
+                const float* c = T + ec * 32 + c8 * 8;
+                const int sa = ((ea >> 1) & 1) ? p.t_swap : 0, sc = ((ec >> 1) & 1) ? p.t_swap : 0;  // stage A's half swap
+                const f32x4 a0 = *(const f32x4*)(a + sa), a1 = *(const f32x4*)(a + (4 ^ sa)), c0 = *(const f32x4*)(c + sc), c1 = *(const f32x4*)(c + (4 ^ sc));
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float r[2], hh[2];
@@ -301,6 +311,7 @@ extern "C" int ufm_dpt_tail_fused(const uint16_t* in, int B, int h, int w, int C
     UFM_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)w2 % 16) == 0 && ((uintptr_t)wt % 16) == 0 && ((uintptr_t)b2 % 16) == 0,
                 "ufm_dpt_tail_fused: misaligned pointer");
     TailFusedArgs p{};
+    p.t_swap = (ufm_upsample_variant_flags() & 2) ? 0 : 4;
     p.in = in, p.w2 = w2, p.b2 = b2, p.wt = wt, p.bt = bt, p.out = out, p.out_logits = out_logits;
     UFM_REQUIRE(in_plane == 0 || in_plane >= (int64_t)B * h * w * CIN, "ufm_dpt_tail_fused: in_plane is shorter than the %d images", B);
     p.in_plane = in_plane ? (long long)in_plane : (long long)B * h * w * CIN, p.w_plane = (long long)CMID * 9 * CIN;

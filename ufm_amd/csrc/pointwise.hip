@@ -454,9 +454,12 @@ extern "C" int ufm_patchify(const void* img, int in_dtype, int in_layout, int B,
     return UFM_OK;
 }
 
-static int g_upsample_tiled = 1;  // A/B and test hook below: 0 = one-thread-per-output kernels only
+static int g_upsample_tiled = 1;  // A/B and test hook below: bit 0 clear = one-thread-per-output kernels only
+static int g_upsample_flags = 1;  // bit 1: ufm_dpt_tail_fused with the plain (2-way bank-conflicting) T image of rounds 1-4
+int ufm_upsample_variant_flags() { return g_upsample_flags; }
 extern "C" int ufm_debug_set_upsample_variant(int tiled) {
-    g_upsample_tiled = tiled;
+    g_upsample_flags = tiled;
+    g_upsample_tiled = tiled & 1;
     return UFM_OK;
 }
 
