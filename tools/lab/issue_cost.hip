@@ -5,21 +5,27 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define REP 64
 
 // VARIANT bits: 1 = MFMA (AGPR acc), 2 = MFMA with VGPR C/D instead, 4 = 2 x v_exp, 8 = 2 x v_add (two chains),
 // 16 = v_cvt_pk, 32 = one global_load_lds per 4 gaps, 64 = A and B operands from AGPRs, 128: one ds_read_b128 per gap,
 // 256: a further ds_read_b128 every second gap (1.5 reads per gap: the 8-wave x 32-row attention layout's ratio)
+// 512 (round 5): the gap's matrix work as TWO v_mfma_f32_16x16x32_bf16 (the same FLOPs as one 32x32x16) -- the shape the guide's
+//      "DVFS give-back" item 7 says the chip clocks higher on; the program also prints the clock each variant held
+//      (delta s_memtime / delta s_memrealtime), so a cycle loss can be set against a clock gain
 template <int V>
 __global__ __launch_bounds__(1024) void k(const char* g, unsigned long long* out, float* sink) {
     __shared__ __attribute__((aligned(16))) char smem[64 * 1024];
     const int lane = threadIdx.x & 63;
     f32x16 acc = {0}, accv = {0};
+    f32x4 acc4a = {0}, acc4b = {0};
     bf16x8 a = {1, 2, 3, 4, 5, 6, 7, 8}, b = {8, 7, 6, 5, 4, 3, 2, 1};
     bf16x8 aa = a, ab = b;
     float x0 = lane * 0.01f, x1 = lane * 0.02f, s0 = 0.f, s1 = 0.f, e0 = 0.f, e1 = 0.f;
@@ -27,10 +33,15 @@ __global__ __launch_bounds__(1024) void k(const char* g, unsigned long long* out
     bf16x8 ld = {0}, ldv[8], ldw[4];
     const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)((__attribute__((address_space(3))) void*)(smem)) + (threadIdx.x >> 6) * 1024);
     unsigned long long t0, t1;
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
     for (int r = 0; r < REP; ++r) {
 #pragma unroll
         for (int gp = 0; gp < 8; ++gp) {
+            if (V & 512) {
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc4a) : "v"(a), "v"(b));
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc4b) : "v"(a), "v"(b));
+            }
             if (V & 1) {
                 if (V & 64) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(aa), "a"(ab));
                 else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
@@ -60,6 +71,8 @@ __global__ __launch_bounds__(1024) void k(const char* g, unsigned long long* out
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) out[256 + blockIdx.x] = ((t1 - t0) * 1000ull) / (rt1 - rt0 ? rt1 - rt0 : 1);  // cycles per 10 ns x 1000 = MHz x 10
     if (lane == 0) {  // block time = first start .. last end over its waves (older waves win issue arbitration)
         __shared__ unsigned long long tmin, tmax;
         if (threadIdx.x == 0) { tmin = ~0ull; tmax = 0; }
@@ -70,17 +83,23 @@ __global__ __launch_bounds__(1024) void k(const char* g, unsigned long long* out
         if (threadIdx.x == 0) out[blockIdx.x] = tmax - tmin;
     }
     float keep = s0 + s1 + e0 + e1 + accv[0] + accv[5] + __uint_as_float(pk) + (float)ld[0];
-    asm volatile("" ::"a"(acc));  // keep the accumulator chain alive
+    asm volatile("" ::"a"(acc), "a"(acc4a), "a"(acc4b));  // keep the accumulator chains alive
     if (keep == 123.456f) sink[0] = keep;
 }
 
 static int g_threads = 256;
+static int g_launches = 3;   // LOAD=1: a few thousand back-to-back launches first, so the clock is the one held under load
+static double g_clock_ghz = 0;
 template <int V>
 double run(const char* g, unsigned long long* d_out, float* sink, std::vector<unsigned long long>& h) {
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k<V>), dim3(256), dim3(g_threads), 0, 0, g, d_out, sink);
+    for (int i = 0; i < g_launches; ++i) hipLaunchKernelGGL((k<V>), dim3(256), dim3(g_threads), 0, 0, g, d_out, sink);
     hipDeviceSynchronize();
-    hipMemcpy(h.data(), d_out, h.size() * 8, hipMemcpyDeviceToHost);
+    std::vector<unsigned long long> all(512);
+    hipMemcpy(all.data(), d_out, 512 * 8, hipMemcpyDeviceToHost);
+    std::copy(all.begin(), all.begin() + 256, h.begin());
     std::sort(h.begin(), h.end());
+    std::sort(all.begin() + 256, all.end());
+    g_clock_ghz = (double)all[256 + 128] / 10000.0;
     return (double)h[h.size() / 2] / (REP * 8);
 }
 
@@ -90,10 +109,24 @@ int main() {
     float* sink;
     hipMalloc(&g, 1 << 20);
     hipMemset(g, 0, 1 << 20);
-    hipMalloc(&d_out, 256 * 8);
+    hipMalloc(&d_out, 512 * 8);
     hipMalloc(&sink, 64);
     std::vector<unsigned long long> h(256);
-#define R(V, name) printf("%-58s %7.2f cycles/gap\n", name, run<V>(g, d_out, sink, h));
+#define R(V, name) { const double c_ = run<V>(g, d_out, sink, h); printf("%-58s %7.2f cycles/gap   clock %.2f GHz   %.2f ns/gap\n", name, c_, g_clock_ghz, c_ / g_clock_ghz); }
+    if (getenv("SHAPE")) {  // round 5: the attention gap with its matrix work as one 32x32x16 or two 16x16x32 MFMAs, clock held under load
+        g_launches = 4000;
+        g_threads = 256;
+        printf("-- 1 wave per SIMD, 4000 launches each (clock under load); one 32x32x16 vs two 16x16x32 per gap --\n");
+        R(1, "mfma 32x32x16");
+        R(512, "2 x mfma 16x16x32");
+        R(1 | 4 | 8 | 16, "mfma 32x32x16 + 2 exp + 2 add + cvt");
+        R(512 | 4 | 8 | 16, "2 x mfma 16x16x32 + 2 exp + 2 add + cvt");
+        R(1 | 4 | 8 | 16 | 128, "mfma 32x32x16 + 2 exp + 2 add + cvt + ds_read_b128");
+        R(512 | 4 | 8 | 16 | 128, "2 x mfma 16x16x32 + 2 exp + 2 add + cvt + ds_read_b128");
+        R(1 | 4 | 8 | 16 | 32 | 128, "mfma 32x32x16 + softmax + ds_read + glds/4 gaps");
+        R(512 | 4 | 8 | 16 | 32 | 128, "2 x mfma 16x16x32 + softmax + ds_read + glds/4 gaps");
+        return 0;
+    }
     for (int thr : {512, 1024}) {  // 2 and 4 waves per SIMD: cycles per gap PER WAVE
         g_threads = thr;
         printf("-- %d waves per SIMD --\n", thr / 256);
