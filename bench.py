@@ -142,6 +142,9 @@ def order_line(line: dict, pairs_per_step: int) -> dict:
     if "roofline" in line and "clock_ghz" in line["roofline"]:
         summary["clock_ghz"] = round(line["roofline"]["clock_ghz"], 3)
         summary["roofline_frac_at_clock"] = round(line["roofline"]["frac_at_clock"], 4)
+        cv = (kernels or {}).get("ufm_conv2d_nhwc_bf16x3", {})
+        if "clock_ghz" in cv:
+            summary["conv_clock_ghz"], summary["conv_frac_at_clock"] = round(cv["clock_ghz"], 3), round(cv["frac_at_clock"], 4)
     for k in ("config4", "config5"):
         if k in line:
             c = line[k]
@@ -257,8 +260,37 @@ def gemm_clock_under_load(hip) -> dict:
     d = buf.view(rows, 8).cpu()
     d = d[d[:, 4] != 0].double()
     clock = float(((d[:, 4] - d[:, 2]) / (d[:, 6] - d[:, 5]).clamp_min(1.0) * 0.1).median())
-    return {"clock_ghz": clock, "workgroups": int(d.shape[0]),
-            "how": "median over workgroups of delta s_memtime / delta s_memrealtime in the stamped fc1 / proj / fc2 instantiations, after 2 s of the encoder block's four GEMMs back to back (random data)"}
+    del ops
+    # the same for the heads' dominant layer, the 148^2 256 -> 256 3x3 residual convolution on the 8-phase bf16x3 kernel
+    Bc, Hc, Cc = 8, 148, 256
+    x = torch.randn(2, Bc, Hc, Hc, Cc, device="cuda").bfloat16()
+    x[1] *= 2.0 ** -9
+    w = (torch.randn(2, Cc, 3, 3, Cc, device="cuda") * (9 * Cc) ** -0.5).bfloat16()
+    w[1] *= 2.0 ** -9
+    bias, res1 = torch.randn(Cc, device="cuda") * 0.1, torch.randn(2, Bc, Hc, Hc, Cc, device="cuda").bfloat16()
+    out, zero = torch.empty(2, Bc, Hc, Hc, Cc, device="cuda", dtype=torch.bfloat16), torch.zeros(256, device="cuda")
+
+    def conv():
+        hip.conv2d_x3(x, Bc, Hc, Hc, Cc, w, Cc, 3, 3, 1, 1, out, zero, bias=bias, res1=res1)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 2.0:
+        for _ in range(20):
+            conv()
+        torch.cuda.synchronize()
+    buf.zero_()
+    hip._check(hip.lib().ufm_debug_set_conv_stamps(buf.data_ptr(), rows), "ufm_debug_set_conv_stamps")
+    try:
+        for _ in range(10):
+            conv()
+        torch.cuda.synchronize()
+    finally:
+        hip._check(hip.lib().ufm_debug_set_conv_stamps(None, 0), "ufm_debug_set_conv_stamps")
+    dc = buf.view(rows, 8).cpu()
+    dc = dc[dc[:, 4] != 0].double()
+    conv_clock = float(((dc[:, 4] - dc[:, 2]) / (dc[:, 6] - dc[:, 5]).clamp_min(1.0) * 0.1).median()) if dc.shape[0] else None
+    return {"clock_ghz": clock, "workgroups": int(d.shape[0]), "conv_clock_ghz": conv_clock,
+            "how": "median over workgroups of delta s_memtime / delta s_memrealtime in the stamped fc1 / proj / fc2 instantiations, after 2 s of the encoder block's four GEMMs back to back (random data); "
+                   "conv_clock_ghz: the same stamps in the 8-phase bf16x3 convolution kernel after 2 s of the 148^2 256->256 3x3 residual layer"}
 
 
 def p50_ms(fn, iters: int, warm: int) -> float:
@@ -661,6 +693,10 @@ def main():
         line["roofline"]["clock_ghz"] = clk["clock_ghz"]
         line["roofline"]["frac_at_clock"] = line["roofline"]["achieved"] / (line["roofline"]["peak"] * clk["clock_ghz"] / 2.4)
         line["roofline"]["clock_source"] = clk["how"]
+        cv = line.get("kernels", {}).get("ufm_conv2d_nhwc_bf16x3")
+        if cv is not None and clk.get("conv_clock_ghz"):
+            cv["clock_ghz"] = clk["conv_clock_ghz"]
+            cv["frac_at_clock"] = cv["achieved"] / (cv["peak"] * clk["conv_clock_ghz"] / 2.4)
 
     if rank == 0:
         print(json.dumps(order_line(line, B)))

@@ -153,6 +153,8 @@ int ufm_debug_set_gemm_tile_rows(int rows);
  * after the last store completed, s_memrealtime (100 MHz) at entry, at the end, s_memtime after the prologue}.  The buffer
  * is read by no kernel.  buf = NULL, rows = 0 turns it off.  tools/lab/gemm_stamps.py. */
 int ufm_debug_set_gemm_stamps(unsigned long long* buf, int rows);
+/* The same for the 256 px x 256 cout 8-phase kernel of ufm_conv2d_nhwc_bf16x3 / ufm_gemm_bf16x3 (every launch of it while set). */
+int ufm_debug_set_conv_stamps(unsigned long long* buf, int rows);
 /* Tuning hook, bit mask: bit 0 -- ufm_attention_bf16 (scale == 0 form) with 2 waves per workgroup instead of 4 (default);
  * bit 1 -- ufm_attention_bf16x3 / ufm_cross_attention_bf16x3 on the round-1 kernel (attention_bf16x3.hip) instead of round 5's
  * LDS-DMA kernel (attention_bf16x3_pw.hip); the two agree bit for bit. */

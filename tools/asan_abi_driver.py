@@ -61,6 +61,8 @@ expect((-1,), lib.ufm_cross_attention_bf16(P, 64, P, P, 64, P, 64, 1, 64, 64, 1,
 expect((-1,), lib.ufm_cross_attention_bf16(P, 64, P, P, 64, P, 66, 1, 64, 64, 1, 0.125, None), "cross scale>0 ldo % 4")
 expect((-1,), lib.ufm_debug_set_gemm_stamps(P, 0), "stamps buffer without rows")
 expect((0,), lib.ufm_debug_set_gemm_stamps(None, 0), "stamps off")
+expect((-1,), lib.ufm_debug_set_conv_stamps(None, 5), "conv stamps rows without buffer")
+expect((0,), lib.ufm_debug_set_conv_stamps(None, 0), "conv stamps off")
 expect((-1,), lib.ufm_gather_rows_f32(P, 62, P, 4, 64, P, 64, None), "gather ld")
 expect((-1,), lib.ufm_debug_set_gemm_variant(3), "variant")
 expect((-1,), lib.ufm_debug_set_gemm_tile_rows(100), "tile rows")

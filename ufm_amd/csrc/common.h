@@ -111,3 +111,38 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
     int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + local;
 }
+
+// In-kernel stamps of the 8-phase GEMM / convolution kernels (cdna_hip_programming.md section 7; MI355X_MICROARCH.md "DVFS give-back" item 6).  Diagnostic instantiations
+// only: the shipped kernels execute no stamp.  Row of workgroup b (8 x uint64), written by its first lane into a buffer of its own:
+//   0: blockIdx | HW_ID << 32      1: XCC_ID | LDS_ALLOC << 32      2: s_memtime at entry      3: s_memtime after the K loop
+//   4: s_memtime after the epilogue's last store has completed      5: s_memrealtime (100 MHz) at entry      6: s_memrealtime at the end
+//   7: s_memtime after the prologue (first fragments readable)
+static __device__ __forceinline__ unsigned long long gemm_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+struct GemmStamps {
+    unsigned long long t_entry, t_prologue, t_loop, rt_entry;
+    __device__ __forceinline__ void entry() {
+        t_entry = gemm_stamp();
+        rt_entry = __builtin_amdgcn_s_memrealtime();
+    }
+    __device__ __forceinline__ void finish(unsigned long long* buf, int rows) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_end = gemm_stamp(), rt_end = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0 && (int)blockIdx.x < rows) {
+            unsigned hw, xcc, lds;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(lds));
+            unsigned long long* d = buf + (size_t)blockIdx.x * 8;
+            d[0] = (unsigned long long)blockIdx.x | ((unsigned long long)hw << 32);
+            d[1] = (unsigned long long)xcc | ((unsigned long long)lds << 32);
+            d[2] = t_entry, d[3] = t_loop, d[4] = t_end, d[5] = rt_entry, d[6] = rt_end, d[7] = t_prologue;
+        }
+    }
+};
+

@@ -244,6 +244,16 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void conv_x3_kernel(ConvX3Arg
 
 }  // namespace
 
+// Diagnostics (bench.py's clock leg, tools/lab): while a buffer is set, launches of the 8-phase convolution kernel run its stamped
+// instantiation and write one 8 x uint64 row per workgroup < rows (common.h GemmStamps); nullptr = off (the default).
+static unsigned long long* g_conv_stamps = nullptr;
+static int g_conv_stamp_rows = 0;
+extern "C" int ufm_debug_set_conv_stamps(unsigned long long* buf, int rows) {
+    UFM_REQUIRE((buf == nullptr) == (rows == 0) && rows >= 0, "ufm_debug_set_conv_stamps: buffer and row count must be given together");
+    g_conv_stamps = buf;
+    g_conv_stamp_rows = rows;
+    return UFM_OK;
+}
 static int g_conv_variant_all = 0;
 // test/tuning hook: 0 = auto, 1 = 128-row kernels only, 2 = 8-phase kernel wherever it is applicable,
 // 3 = 128-row kernels only and never the deep (NS = 4) ring; + 16 = the serial (per-pass) residual read-out of rounds 1-4
@@ -280,6 +290,7 @@ extern "C" long long ufm_conv_x3_splitk_ws_bytes(int groups, int B, int H, int W
 static void launch_conv_x3(const ConvX3Args& p_in, int passes, hipStream_t stream) {
     ConvX3Args p = p_in;
     p.serial_epilogue = (g_conv_variant_all >> 4) & 1;
+    p.stamps = g_conv_stamps, p.stamp_rows = g_conv_stamp_rows;
     const int g_conv_variant = g_conv_variant_all & 15;
     const int Cout = p.Cout, KH = p.KH, KW = p.KW, Cin = p.Cin;
     const long long M = p.M;

@@ -32,9 +32,11 @@ struct TapIter {  // walks the K-tiles of one half-tile kind: channel-chunk oute
     int tap, kh, kw, c0;
 };
 
-template <int WR, int WC>
+template <int WR, int WC, bool STAMP = false>
 __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
     static_assert(WR * WC == 8, "eight waves");
+    GemmStamps stamps;  // (diagnostic instantiation only: the shipped kernel executes no stamp)
+    if constexpr (STAMP) stamps.entry(), stamps.t_prologue = stamps.t_entry;
     constexpr int XROWS = WR * 64, WROWS = WC * 32;           // rows of an X / W half-tile
     constexpr int XPLANE = XROWS * 64, WPLANE = WROWS * 64;   // bytes of one plane
     constexpr int XHALF = 2 * XPLANE, WHALF = 2 * WPLANE;
@@ -245,9 +247,11 @@ __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
 
     if (wr == 0) __builtin_amdgcn_s_barrier();  // pairs with the last M-slot barrier of the wr = 1 group
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (STAMP) stamps.t_loop = gemm_stamp();
     // two explicit calls: a loop over h that hipcc declines to unroll would index acc[h] at run time -> scratch (rule 20)
     conv_x3_epilogue<4, 4>(p, acc[0], smem + wave * 16384, m0 + wr * 128, n0 + wc * 64, lane, grp);
     conv_x3_epilogue<4, 4>(p, acc[1], smem + wave * 16384, m0 + wr * 128 + 64, n0 + wc * 64, lane, grp);
+    if constexpr (STAMP) stamps.finish(p.stamps, p.stamp_rows);
 }
 
 }  // namespace
@@ -257,6 +261,7 @@ int ufm_launch_conv_x3_8ph(const ConvX3Args& p, hipStream_t stream) {
     // 128 cout for Cout = 128) measured slower than the 128-row kernels (296^2 256->128: 1328 vs 1130 us) and is no longer
     // instantiated.
     const int ntm = (p.M - p.m_begin + 255) / 256 * p.groups;
-    hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4>), dim3(ntm * (p.Cout / 256)), dim3(512), 0, stream, p);
+    if (p.stamps) hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4, true>), dim3(ntm * (p.Cout / 256)), dim3(512), 0, stream, p);  // diagnostic build
+    else hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4>), dim3(ntm * (p.Cout / 256)), dim3(512), 0, stream, p);
     return 0;
 }

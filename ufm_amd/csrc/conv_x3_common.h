@@ -35,6 +35,9 @@ struct ConvX3Args {
     float* slab;          // [tiles][splitk][BM * BN] partial tiles (fragment order)
     unsigned* counters;   // [tiles], zero between launches (the last arriver resets its tile's word)
     int serial_epilogue;  // A/B hook (ufm_debug_set_conv_variant bit 4): the per-pass residual read-out of rounds 1-4
+    // diagnostic build only (ufm_debug_set_conv_stamps; the STAMP = true instantiation of the 8-phase kernel): 8 x uint64 per workgroup
+    unsigned long long* stamps;
+    int stamp_rows;
 };
 
 // tile row index over all groups -> (group, tile row inside the group); tiles_pg = row tiles per group of this launch

@@ -41,6 +41,7 @@ SIGNATURES = {
     "ufm_debug_set_gemm_flags": [_i],
     "ufm_debug_set_gemm_tile_rows": [_i],
     "ufm_debug_set_gemm_stamps": [_vp, _i],
+    "ufm_debug_set_conv_stamps": [_vp, _i],
     "ufm_debug_set_attn_variant": [_i],
     "ufm_debug_set_conv_variant": [_i],
     "ufm_debug_set_upsample_variant": [_i],
