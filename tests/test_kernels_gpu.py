@@ -948,6 +948,7 @@ def test_fill_uv_and_bilinear_resize_into_concat_buffer(hip, fmt):
         (300, 64, 96, 1, True, False, True),            # GELU (exact erf), 128x64 tiles
         (257, 128, 64, 0, True, True, False),           # LayerScale + fp32 residual in place
         (2 * 1370, 3072, 1024, 0, True, False, True),   # QKV shape: 8-phase 256x256 tiles + remainder
+        (1370, 4096, 1024, 1, False, False, True),      # fc1 shape: GELU + split store on whole 8-phase tiles (the grouped store-only epilogue)
         (2 * 1370, 1024, 4096, 0, True, True, False),   # fc2 shape
         (8 * 1369 + 5, 768, 768, 0, False, True, False),
     ],
@@ -988,6 +989,15 @@ def test_gemm_bf16x3(hip, M, N, K, act, use_gamma, use_res, split_out):
         finally:
             lib.ufm_debug_set_conv_variant(0)
         assert torch.equal(out2, out)
+    if split_out:  # ... and of the store-only split form (mode 4; with the GELU: fc1), likewise against the serial read-out
+        lib = hip.lib()
+        try:
+            lib.ufm_debug_set_conv_variant(16)
+            out2 = torch.full((2, M, N), 7.0, device=DEV, dtype=torch.bfloat16)
+            hip.gemm_x3(As.to(DEV), Ws.to(DEV), M, N, K, out2, zero, bias=bias.to(DEV), act=act, gamma=gamma.to(DEV) if gamma is not None else None)
+        finally:
+            lib.ufm_debug_set_conv_variant(0)
+        assert torch.equal(out2.view(torch.int16), out.view(torch.int16))
 
 
 def test_split_format_gelu_epilogue_against_fp64_gelu(hip):

@@ -291,6 +291,7 @@ static void launch_conv_x3(const ConvX3Args& p_in, int passes, hipStream_t strea
     ConvX3Args p = p_in;
     p.serial_epilogue = (g_conv_variant_all >> 4) & 1;
     p.stamps = g_conv_stamps, p.stamp_rows = g_conv_stamp_rows;
+    p.mfma_order = (g_conv_variant_all >> 5) & 1;
     const int g_conv_variant = g_conv_variant_all & 15;
     const int Cout = p.Cout, KH = p.KH, KW = p.KW, Cin = p.Cin;
     const long long M = p.M;

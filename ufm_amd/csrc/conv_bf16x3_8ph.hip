@@ -32,7 +32,10 @@ struct TapIter {  // walks the K-tiles of one half-tile kind: channel-chunk oute
     int tap, kh, kw, c0;
 };
 
-template <int WR, int WC, bool STAMP = false>
+// ORD = order of a phase's 24 MFMAs: 0 = the three products of an accumulator back to back (rounds 1-4), 1 = product-major over the
+// phase's eight accumulators (lo*hi of all, hi*lo of all, hi*hi of all).  Every accumulator sees its three products in the same
+// order either way: bit-identical.
+template <int WR, int WC, bool STAMP = false, int ORD = 0>
 __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
     static_assert(WR * WC == 8, "eight waves");
     GemmStamps stamps;  // (diagnostic instantiation only: the shipped kernel executes no stamp)
@@ -173,15 +176,27 @@ __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
             }
         }
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (ORD == 0) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                f32x4& a = acc[MH][NH * 2 + j][i];
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][1], xf[i][0], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][0], xf[i][1], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][0], xf[i][0], a, 0, 0, 0);
-            }
+                for (int i = 0; i < 4; ++i) {
+                    f32x4& a = acc[MH][NH * 2 + j][i];
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][1], xf[i][0], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][0], xf[i][1], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][0], xf[i][0], a, 0, 0, 0);
+                }
+        } else {
+#pragma unroll
+            for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        f32x4& a = acc[MH][NH * 2 + j][i];
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][pass == 0 ? 1 : 0], xf[i][pass == 1 ? 1 : 0], a, 0, 0, 0);
+                    }
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -261,7 +276,11 @@ int ufm_launch_conv_x3_8ph(const ConvX3Args& p, hipStream_t stream) {
     // 128 cout for Cout = 128) measured slower than the 128-row kernels (296^2 256->128: 1328 vs 1130 us) and is no longer
     // instantiated.
     const int ntm = (p.M - p.m_begin + 255) / 256 * p.groups;
-    if (p.stamps) hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4, true>), dim3(ntm * (p.Cout / 256)), dim3(512), 0, stream, p);  // diagnostic build
-    else hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4>), dim3(ntm * (p.Cout / 256)), dim3(512), 0, stream, p);
+    const dim3 grid(ntm * (p.Cout / 256)), block(512);
+    if (p.mfma_order) {  // A/B (ufm_debug_set_conv_variant bit 5)
+        if (p.stamps) hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4, true, 1>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4, false, 1>), grid, block, 0, stream, p);
+    } else if (p.stamps) hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4, true>), grid, block, 0, stream, p);  // diagnostic build
+    else hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4>), grid, block, 0, stream, p);
     return 0;
 }

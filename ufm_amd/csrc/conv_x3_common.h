@@ -38,6 +38,7 @@ struct ConvX3Args {
     // diagnostic build only (ufm_debug_set_conv_stamps; the STAMP = true instantiation of the 8-phase kernel): 8 x uint64 per workgroup
     unsigned long long* stamps;
     int stamp_rows;
+    int mfma_order;  // A/B hook (ufm_debug_set_conv_variant bit 5): product-major MFMA order in the 8-phase kernel
 };
 
 // tile row index over all groups -> (group, tile row inside the group); tiles_pg = row tiles per group of this launch
@@ -107,16 +108,21 @@ static __device__ __forceinline__ void conv_x3_epilogue(const ConvX3Args& p, f32
     // (ufm_gemm_bf16x3's proj / fc2), one or two split residuals (the RCU / fusion-block convolutions) -- the loads of a group of
     // passes are issued first, then the group's arithmetic and stores.  Same operations in the same order per element: bit-identical.
     constexpr int PASSES = TM * 16 / RPI;
-    const int mode = (p.shuffle || pix0 + TM * 16 > p.M || p.act == UFM_ACT_GELU) ? 0
-                     : (p.out_f32 ? (p.res_f32 ? 3 : 0) : (p.res1 ? (p.res2 ? 2 : 1) : 0));
+    // mode 4 (round 5, second step): split output WITHOUT a residual -- most layers of the heads and the precise-mode QKV / fc1.  No loads
+    // to pipeline there, but the general loop's per-pass `continue` and run-time switches still cost: the stamps show 44 k cycles of
+    // epilogue per 256 x 256 tile for a store-only layer against 28 k for the grouped residual form (tools/lab/conv_stamps.py).
+    const bool gelu = p.act == UFM_ACT_GELU;
+    const int mode = (p.shuffle || pix0 + TM * 16 > p.M || (gelu && (p.out_f32 || p.res1))) ? 0
+                     : (p.out_f32 ? (p.res_f32 ? 3 : 0) : (p.res1 ? (p.res2 ? 2 : 1) : 4));
     if (mode != 0 && !p.serial_epilogue) {
         const int cb = cb0 + oc * 4;
         const float lo = (p.act == UFM_ACT_RELU) ? 0.0f : -__builtin_inff();  // fmaxf(v, -inf) == v
         f32x4 gv = {1.f, 1.f, 1.f, 1.f};
         __builtin_amdgcn_s_waitcnt(0x0F70);  // compiler-visible vmcnt(0): clears the K loop's LDS-DMA from hipcc's scoreboard (all landed)
         if (p.gamma) gv = *(const f32x4*)(p.gamma + cb);
-        auto body = [&](auto mode_c) {
+        auto body = [&](auto mode_c, auto gelu_c) {
             constexpr int MODE = decltype(mode_c)::value;
+            constexpr bool GELU = decltype(gelu_c)::value;
             constexpr int G = MODE == 2 ? (PASSES < 8 ? PASSES : 8) : PASSES;  // passes per group: <= 64 registers of loads in flight
 #pragma unroll
             for (int g0 = 0; g0 < PASSES; g0 += G) {
@@ -135,8 +141,13 @@ static __device__ __forceinline__ void conv_x3_epilogue(const ConvX3Args& p, f32
                     const int r = (g0 + i) * RPI + orr;
                     const size_t o = (size_t)(row0 + pix0 + r) * p.Cout + cb;
                     f32x4 v = *(const f32x4*)(ws + r * ROWB + ((oc ^ (r & (NCH - 1))) << 4));
+                    if constexpr (GELU) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], lo);
+                        for (int j = 0; j < 4; ++j) v[j] = gelu_erf_fast(v[j]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], lo);
+                    }
                     v *= gv;
                     auto unsplit = [](const u32x2& ph, const u32x2& pl) {
                         f32x4 x;
@@ -150,7 +161,7 @@ static __device__ __forceinline__ void conv_x3_epilogue(const ConvX3Args& p, f32
                         v += rf[i];
                         *(f32x4*)(p.out_f32 + o) = v;
                     } else {
-                        v += unsplit(h1[i], l1[i]);
+                        if constexpr (MODE == 1 || MODE == 2) v += unsplit(h1[i], l1[i]);
                         if constexpr (MODE == 2) v += unsplit(h2[i], l2[i]);
                         split_store4(p.out + o, p.out_plane, v);
                         if (p.out_relu) {
@@ -163,9 +174,13 @@ static __device__ __forceinline__ void conv_x3_epilogue(const ConvX3Args& p, f32
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        if (mode == 3) body(std::integral_constant<int, 3>{});
-        else if (mode == 2) body(std::integral_constant<int, 2>{});
-        else body(std::integral_constant<int, 1>{});
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+        if (mode == 3) body(std::integral_constant<int, 3>{}, F_{});
+        else if (mode == 2) body(std::integral_constant<int, 2>{}, F_{});
+        else if (mode == 1) body(std::integral_constant<int, 1>{}, F_{});
+        else if (gelu) body(std::integral_constant<int, 4>{}, T_{});
+        else body(std::integral_constant<int, 4>{}, F_{});
         return;
     }
 #pragma unroll
