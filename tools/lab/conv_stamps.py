@@ -7,8 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from ufm_amd import hip
 lib = hip.lib()
 B = 8
-SHAPES = [(148, 256, 256, 3, 1), (74, 256, 256, 3, 1), (148, 96, 256, 3, 0)]
-VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "2,34").split(",")]
+SHAPES = [(148, 256, 256, 3, 1), (74, 256, 256, 3, 1), (148, 96, 256, 3, 0), (74, 192, 256, 3, 0), (37, 256, 256, 3, 1)]
+VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "0,2").split(",")]
 for h, cin, cout, k, nres in SHAPES:
     x = torch.randn(2, B, h, h, cin, device="cuda").bfloat16(); x[1] *= 2.0 ** -9
     w = (torch.randn(2, cout, k, k, cin, device="cuda") * (cin * k * k) ** -0.5).bfloat16(); w[1] *= 2.0 ** -9
@@ -42,6 +42,9 @@ for h, cin, cout, k, nres in SHAPES:
         torch.cuda.synchronize()
         hip._check(lib.ufm_debug_set_conv_stamps(None, 0), "stamps")
         d = buf.view(rows, 8).cpu(); d = d[d[:, 4] != 0].double()
+        if d.shape[0] == 0:  # no stamped instantiation ran (a lower tile height, or the 128-row kernels)
+            res[v] = dict(us=round(us, 1), tf_alg=round(fl / us / 1e6), frac_of_third_peak=round(fl / us / 1e6 / 833.3, 3))
+            continue
         clock = float(((d[:, 4] - d[:, 2]) / (d[:, 6] - d[:, 5]).clamp_min(1) * 0.1).median())
         loop, epi = float((d[:, 3] - d[:, 2]).median()), float((d[:, 4] - d[:, 3]).median())
         nk = k * k * cin // 32

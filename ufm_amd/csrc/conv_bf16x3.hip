@@ -291,7 +291,7 @@ static void launch_conv_x3(const ConvX3Args& p_in, int passes, hipStream_t strea
     ConvX3Args p = p_in;
     p.serial_epilogue = (g_conv_variant_all >> 4) & 1;
     p.stamps = g_conv_stamps, p.stamp_rows = g_conv_stamp_rows;
-    p.mfma_order = (g_conv_variant_all >> 5) & 1;
+    const int nf_pin = (g_conv_variant_all >> 8) & 15;  // tools / tests: pin the 8-phase tile height (5..8 fragments per wave row)
     const int g_conv_variant = g_conv_variant_all & 15;
     const int Cout = p.Cout, KH = p.KH, KW = p.KW, Cin = p.Cin;
     const long long M = p.M;
@@ -340,7 +340,7 @@ static void launch_conv_x3(const ConvX3Args& p_in, int passes, hipStream_t strea
     if (passes == 1 || S > 1) {  // (split-K lives in the 128- / 64-row kernels: its layers are the small maps the 8-phase tile never fits)
         launch128(p);
     } else if (ok8 && g_conv_variant == 2) {
-        ufm_launch_conv_x3_8ph(p, stream);
+        ufm_launch_conv_x3_8ph(p, stream, nf_pin >= 5 && nf_pin <= 8 ? nf_pin : 8);
     } else if (ok8 && g_conv_variant == 0 && t8 >= ufm_device_cu_count() / 2 && KH * KW * (Cin / 32) >= 16) {  // (variants 1 and 3 never take this branch)
         // Measured per shape (tools/lab/conv_rounds.py, profiles/r03/conv_rounds.log): a last partial round of at least half
         // the chip is cheaper on the 8-phase kernel than on the 128-row kernels (148^2 RCU, 684 tiles: 485 vs 518 us; 74^2 RCU,
@@ -349,8 +349,30 @@ static void launch_conv_x3(const ConvX3Args& p_in, int passes, hipStream_t strea
         const long long ncu = ufm_device_cu_count();
         const long long full = t8 / ncu;                                 // whole rounds of the 8-phase kernel
         const long long m_main = full * ncu / ((long long)(Cout / tile_n) * G) * tile_m;  // leading pixels (of every group) whose tiles fit in them
-        if (m_main >= M || t8 - full * ncu >= ncu / 2) {
-            ufm_launch_conv_x3_8ph(p, stream);
+        // Round 5: tiles of 160 / 192 / 224 rows as well (32 nf rows; conv_bf16x3_8ph.hip).  Cost in units of one round of 256-row tiles,
+        // fitted to tools/lab/gemm_x3_rows.py (profiles/r05/gemm_x3_rows.log): a tile of 32 nf rows costs FIX + (1 - FIX) nf / 8 (prologue,
+        // drain and the barriers of a phase do not shrink with its MFMA count), a launch is whole rounds of the chip; the hybrid form
+        // (256-row tiles on the whole rounds + the 128-row kernels on a last partial round below half the chip) costs its whole rounds
+        // + 0.6 .. 0.95 for the second launch.  M = 10 960 x N = 1024: 172 tiles of 256 rows (two thirds of a round) -> 232 of 192 rows,
+        // 71.8 -> 67.5 us; x 768: 129 tiles -> 207 of 160 rows, 54.4 -> 48.0 us; the N >= 3072 shapes keep the hybrid form.
+        constexpr double FIX = 0.65;
+        double best = 1e30;
+        int best_nf = 8;
+        for (int nf = 8; nf >= 5; --nf) {
+            const long long t = ((M + 32 * nf - 1) / (32 * nf)) * (Cout / tile_n) * G;
+            const double c = (double)((t + ncu - 1) / ncu) * (FIX + (1.0 - FIX) * nf / 8.0);
+            if (c < best - 1e-9) best = c, best_nf = nf;
+        }
+        bool hybrid = false;
+        if (nf_pin >= 5 && nf_pin <= 8) {
+            best_nf = nf_pin;
+        } else if (full >= 1 && m_main < M && t8 - full * ncu < ncu / 2) {
+            const long long blocks128 = ((M - m_main + 127) / 128) * (Cout / 128) * G;
+            const double frac128 = (double)blocks128 / (2.0 * (double)ncu);
+            hybrid = (double)full + 0.6 + 0.35 * (frac128 < 1.0 ? frac128 : 1.0) < best;
+        }
+        if (!hybrid) {
+            ufm_launch_conv_x3_8ph(p, stream, best_nf);
         } else {
             ConvX3Args lead = p, rest = p;
             lead.M = (int)m_main;

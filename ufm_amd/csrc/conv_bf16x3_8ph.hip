@@ -32,12 +32,16 @@ struct TapIter {  // walks the K-tiles of one half-tile kind: channel-chunk oute
     int tap, kh, kw, c0;
 };
 
-// ORD = order of a phase's 24 MFMAs: 0 = the three products of an accumulator back to back (rounds 1-4), 1 = product-major over the
-// phase's eight accumulators (lo*hi of all, hi*lo of all, hi*hi of all).  Every accumulator sees its three products in the same
-// order either way: bit-identical.
-template <int WR, int WC, bool STAMP = false, int ORD = 0>
+// NF = 16-row fragments per wave row (5..8; WR = 2 only): the tile is WR x 16 NF pixels high, as in gemm_bf16_8ph.hip -- a wave's second
+// 64-row half has NF - 4 fragments; staging, schedule and every accumulator's order are those of NF = 8 (bit-identical).  Lower tiles
+// let the Linear layers of numerics "precise" (ufm_gemm_bf16x3: M = 21 920 rows x N = 1024 is 344 tiles of 256 rows on 256 CUs) fill
+// whole rounds of the chip.  (Round 5 also tried the phase's 24 MFMAs product-major over its eight accumulators instead of three
+// per accumulator back to back: neutral, 478.7 vs 479.2 us on the 148^2 layer, tools/lab/conv_stamps.py -- not kept.)
+template <int WR, int WC, bool STAMP = false, int NF = 8>
 __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
     static_assert(WR * WC == 8, "eight waves");
+    static_assert(NF >= 5 && NF <= 8 && (NF == 8 || WR == 2), "NF");
+    constexpr int RW = 16 * NF;  // pixel rows of one wave row
     GemmStamps stamps;  // (diagnostic instantiation only: the shipped kernel executes no stamp)
     if constexpr (STAMP) stamps.entry(), stamps.t_prologue = stamps.t_entry;
     constexpr int XROWS = WR * 64, WROWS = WC * 32;           // rows of an X / W half-tile
@@ -56,10 +60,10 @@ __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tmi_all = bid / ntn, tni = bid - tmi_all * ntn;
     int grp, tmi;
-    conv_x3_group_of(p, tmi_all, (p.M - p.m_begin + WR * 128 - 1) / (WR * 128), grp, tmi);
+    conv_x3_group_of(p, tmi_all, (p.M - p.m_begin + WR * RW - 1) / (WR * RW), grp, tmi);
     const uint16_t* const in_g = p.in + (size_t)grp * p.in_group;
     const uint16_t* const w_g = p.w + (size_t)grp * p.w_group;
-    const int m0 = p.m_begin + tmi * (WR * 128), n0 = tni * (WC * 64);
+    const int m0 = p.m_begin + tmi * (WR * RW), n0 = tni * (WC * 64);
     const int ntaps = p.KH * p.KW;
     const int nt = ntaps * (p.Cin >> 5);
     const unsigned ktot = (unsigned)(ntaps * p.Cin);
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
         x_chunk[i] = (unsigned)((slot ^ swz(lr)) * 8);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int brow = (lr >> 6) * 128 + h * 64 + (lr & 63);  // X half h: pixel rows mh = h of every wave row
+            const int brow = (lr >> 6) * RW + h * 64 + (lr & 63);  // X half h: pixel rows mh = h of every wave row (rows past RW: unused)
             const int m = min(m0 + brow, p.M - 1);
             const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
             x_iy0[h][i] = oy * p.stride - p.pad;
@@ -151,6 +155,7 @@ __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
         const char* s = smem + (tile & 1) * KTILE + half_off(1 + 2 * mh);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            if (mh == 1 && i >= NF - 4) continue;
             xf[i][0] = *(const bf16x8*)(s + x_off[i]);
             xf[i][1] = *(const bf16x8*)(s + XPLANE + x_off[i]);
         }
@@ -169,34 +174,22 @@ __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
         __builtin_amdgcn_sched_barrier(0);
         if (fresh_x && p.relu_in) {  // ReLU on the input: the sign of hi decides for both halves
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < (MH == 0 ? 4 : NF - 4); ++i) {
                 const bf16x8 neg = xf[i][0] >> 15;
                 xf[i][0] &= ~neg;
                 xf[i][1] &= ~neg;
             }
         }
         __builtin_amdgcn_s_setprio(1);
-        if constexpr (ORD == 0) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    f32x4& a = acc[MH][NH * 2 + j][i];
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][1], xf[i][0], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][0], xf[i][1], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][0], xf[i][0], a, 0, 0, 0);
-                }
-        } else {
-#pragma unroll
-            for (int pass = 0; pass < 3; ++pass)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        f32x4& a = acc[MH][NH * 2 + j][i];
-                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][pass == 0 ? 1 : 0], xf[i][pass == 1 ? 1 : 0], a, 0, 0, 0);
-                    }
-        }
+            for (int i = 0; i < (MH == 0 ? 4 : NF - 4); ++i) {
+                f32x4& a = acc[MH][NH * 2 + j][i];
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][1], xf[i][0], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][0], xf[i][1], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][0], xf[i][0], a, 0, 0, 0);
+            }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -264,23 +257,23 @@ __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (STAMP) stamps.t_loop = gemm_stamp();
     // two explicit calls: a loop over h that hipcc declines to unroll would index acc[h] at run time -> scratch (rule 20)
-    conv_x3_epilogue<4, 4>(p, acc[0], smem + wave * 16384, m0 + wr * 128, n0 + wc * 64, lane, grp);
-    conv_x3_epilogue<4, 4>(p, acc[1], smem + wave * 16384, m0 + wr * 128 + 64, n0 + wc * 64, lane, grp);
+    conv_x3_epilogue<4, 4>(p, acc[0], smem + wave * 16384, m0 + wr * RW, n0 + wc * 64, lane, grp);
+    conv_x3_epilogue<4, 4, NF - 4>(p, acc[1], smem + wave * 16384, m0 + wr * RW + 64, n0 + wc * 64, lane, grp);
     if constexpr (STAMP) stamps.finish(p.stamps, p.stamp_rows);
 }
 
 }  // namespace
 
-int ufm_launch_conv_x3_8ph(const ConvX3Args& p, hipStream_t stream) {
-    // 256 px x 256 cout tiles (wave layout 2 x 4).  The kernel is templated on the wave layout; the 4 x 2 layout (512 px x
-    // 128 cout for Cout = 128) measured slower than the 128-row kernels (296^2 256->128: 1328 vs 1130 us) and is no longer
-    // instantiated.
-    const int ntm = (p.M - p.m_begin + 255) / 256 * p.groups;
+int ufm_launch_conv_x3_8ph(const ConvX3Args& p, hipStream_t stream, int nf) {
+    // 256 px x 256 cout tiles (wave layout 2 x 4), 32 nf px high.  The kernel is templated on the wave layout; the 4 x 2 layout (512 px x
+    // 128 cout for Cout = 128) measured slower than the 128-row kernels (296^2 256->128: 1328 vs 1130 us) and is no longer instantiated.
+    const int rows = 32 * nf;
+    const int ntm = (p.M - p.m_begin + rows - 1) / rows * p.groups;
     const dim3 grid(ntm * (p.Cout / 256)), block(512);
-    if (p.mfma_order) {  // A/B (ufm_debug_set_conv_variant bit 5)
-        if (p.stamps) hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4, true, 1>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4, false, 1>), grid, block, 0, stream, p);
-    } else if (p.stamps) hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4, true>), grid, block, 0, stream, p);  // diagnostic build
+    if (p.stamps && nf == 8) hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4, true>), grid, block, 0, stream, p);  // diagnostic build
+    else if (nf == 5) hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4, false, 5>), grid, block, 0, stream, p);
+    else if (nf == 6) hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4, false, 6>), grid, block, 0, stream, p);
+    else if (nf == 7) hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4, false, 7>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4>), grid, block, 0, stream, p);
     return 0;
 }

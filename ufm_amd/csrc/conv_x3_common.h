@@ -38,7 +38,6 @@ struct ConvX3Args {
     // diagnostic build only (ufm_debug_set_conv_stamps; the STAMP = true instantiation of the 8-phase kernel): 8 x uint64 per workgroup
     unsigned long long* stamps;
     int stamp_rows;
-    int mfma_order;  // A/B hook (ufm_debug_set_conv_variant bit 5): product-major MFMA order in the 8-phase kernel
 };
 
 // tile row index over all groups -> (group, tile row inside the group); tiles_pg = row tiles per group of this launch
@@ -79,8 +78,10 @@ static __device__ __forceinline__ f32x4 split_load4(const uint16_t* hi_ptr, long
 // four residual plane loads; staged, a wave instruction covers whole pixel rows (TN*16 consecutive output channels =
 // 128/64 B per plane, contiguous).  Chunk index XOR row keeps both the accumulator-shaped writes and the row-shaped
 // reads conflict-free.  LDS ops of one wave execute in order: no barrier between the writes and the reads.
-template <int TM, int TN>
+// TMU <= TM: only the first TMU 16-row fragments of the accumulator array exist (8-phase tiles lower than 256 rows).
+template <int TM, int TN, int TMU = TM>
 static __device__ __forceinline__ void conv_x3_epilogue(const ConvX3Args& p, f32x4 (&acc)[TN][TM], char* ws, int pix0, int cb0, int lane, int g = 0) {
+    static_assert(TMU >= 1 && TMU <= TM, "TMU");
     // pix0 = first row of the tile INSIDE group g; rows of out / res* are numbered over all groups (row0 = g * Mg)
     const float* bias_g = p.bias ? p.bias + (size_t)g * (p.shuffle ? p.Co : p.Cout) : nullptr;
     const int row0 = g * p.Mg;
@@ -95,7 +96,7 @@ static __device__ __forceinline__ void conv_x3_epilogue(const ConvX3Args& p, f32
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         if (bias_g) bv = *(const f32x4*)(bias_g + (p.shuffle ? cb % p.Co : cb));
 #pragma unroll
-        for (int m = 0; m < TM; ++m) {
+        for (int m = 0; m < TMU; ++m) {
             const int r = m * 16 + fr;
             *(f32x4*)(ws + r * ROWB + (((n * 4 + fq) ^ (r & (NCH - 1))) << 4)) = acc[n][m] + bv;
         }
@@ -107,12 +108,12 @@ static __device__ __forceinline__ void conv_x3_epilogue(const ConvX3Args& p, f32
     // 64-row slice.  For whole slices (no ragged rows, no pixel shuffle) of the three residual forms -- fp32 read-modify-write
     // (ufm_gemm_bf16x3's proj / fc2), one or two split residuals (the RCU / fusion-block convolutions) -- the loads of a group of
     // passes are issued first, then the group's arithmetic and stores.  Same operations in the same order per element: bit-identical.
-    constexpr int PASSES = TM * 16 / RPI;
+    constexpr int PASSES = TMU * 16 / RPI;
     // mode 4 (round 5, second step): split output WITHOUT a residual -- most layers of the heads and the precise-mode QKV / fc1.  No loads
     // to pipeline there, but the general loop's per-pass `continue` and run-time switches still cost: the stamps show 44 k cycles of
     // epilogue per 256 x 256 tile for a store-only layer against 28 k for the grouped residual form (tools/lab/conv_stamps.py).
     const bool gelu = p.act == UFM_ACT_GELU;
-    const int mode = (p.shuffle || pix0 + TM * 16 > p.M || (gelu && (p.out_f32 || p.res1))) ? 0
+    const int mode = (p.shuffle || pix0 + TMU * 16 > p.M || (gelu && (p.out_f32 || p.res1))) ? 0
                      : (p.out_f32 ? (p.res_f32 ? 3 : 0) : (p.res1 ? (p.res2 ? 2 : 1) : 4));
     if (mode != 0 && !p.serial_epilogue) {
         const int cb = cb0 + oc * 4;
@@ -130,6 +131,7 @@ static __device__ __forceinline__ void conv_x3_epilogue(const ConvX3Args& p, f32
                 u32x2 h1[G], l1[G], h2[MODE == 2 ? G : 1], l2[MODE == 2 ? G : 1];
 #pragma unroll
                 for (int i = 0; i < G; ++i) {
+                    if (g0 + i >= PASSES) continue;  // (PASSES = 12 with groups of 8: the lower 8-phase tiles)
                     const size_t o = (size_t)(row0 + pix0 + (g0 + i) * RPI + orr) * p.Cout + cb;
                     if constexpr (MODE == 3) rf[i] = *(const f32x4*)(p.res_f32 + o);
                     if constexpr (MODE == 1 || MODE == 2) h1[i] = *(const u32x2*)(p.res1 + o), l1[i] = *(const u32x2*)(p.res1 + o + p.out_plane);
@@ -138,6 +140,7 @@ static __device__ __forceinline__ void conv_x3_epilogue(const ConvX3Args& p, f32
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < G; ++i) {
+                    if (g0 + i >= PASSES) continue;
                     const int r = (g0 + i) * RPI + orr;
                     const size_t o = (size_t)(row0 + pix0 + r) * p.Cout + cb;
                     f32x4 v = *(const f32x4*)(ws + r * ROWB + ((oc ^ (r & (NCH - 1))) << 4));
@@ -226,4 +229,4 @@ static __device__ __forceinline__ void conv_x3_epilogue(const ConvX3Args& p, f32
 }
 
 // conv_bf16x3_8ph.hip: 8-phase kernels, 256 px x 256 cout (Cout % 256 == 0) or 512 px x 128 cout (Cout % 128 == 0); 32-bit operand offsets
-int ufm_launch_conv_x3_8ph(const ConvX3Args& p, hipStream_t stream);
+int ufm_launch_conv_x3_8ph(const ConvX3Args& p, hipStream_t stream, int nf = 8);  // nf = 16-row fragments per wave row (5..8): tiles of 32 nf pixels
