@@ -42,3 +42,20 @@ e.group_heads = False
 soak(m, 3, "UFM-Base B=3 fast, split-K, two-stream heads")
 e.conv_splitk, e.level_streams, e.level_streams_max_images = False, True, 8
 soak(m, 2, "UFM-Base B=2 fast, level-chain streams")
+# round 5: the 256x128 two-resident-workgroups GEMM on every eligible Linear (gemm flags bit 27), and precise mode on the rebuilt attention kernel
+e.level_streams = False
+from ufm_amd import hip
+hip.lib().ufm_debug_set_gemm_flags(1 << 27)
+soak(m, 8, "UFM-Base B=8 fast, pair GEMM everywhere")
+hip.lib().ufm_debug_set_gemm_flags(0)
+del m
+m = ufm_amd.UniFlowMatchConfidence(**ufm_amd.ufm_base_config(resolution_wh=(1036, 1036))).eval(); init_weights_(m, 0); m = m.to("cuda").set_numerics("precise")
+def soak_big(model, tag):
+    g = torch.Generator().manual_seed(9)
+    src = torch.randint(0, 256, (1, 1036, 1036, 3), dtype=torch.uint8, generator=g).cuda()
+    tgt = torch.randint(0, 256, (1, 1036, 1036, 3), dtype=torch.uint8, generator=g).cuda()
+    o = model.predict_correspondences_batched(src, tgt)
+    f0 = o.flow.flow_output.clone()
+    bad = sum(0 if torch.equal(model.predict_correspondences_batched(src, tgt).flow.flow_output, f0) else 1 for _ in range(max(4, REPS // 10)))
+    print(f"{tag}: {bad} of {max(4, REPS // 10)} repeats differ", flush=True)
+soak_big(m, "UFM-Base 1036^2 B=1 precise (10 954-token joint attention on the round-5 kernel)")
