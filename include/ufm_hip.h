@@ -160,6 +160,7 @@ int ufm_debug_set_conv_stamps(unsigned long long* buf, int rows);
  * LDS-DMA kernel (attention_bf16x3_pw.hip); the two agree bit for bit. */
 int ufm_debug_set_attn_variant(int v);
 /* Tuning hook for ufm_conv2d_nhwc_bf16x3: 0 = auto, 1 = 128-row kernels only, 2 = 256x256 8-phase kernel wherever applicable,
+ * 4 = the 256 px x 128 cout two-resident-workgroups kernel of round 5 (conv_bf16x3_pair.hip) wherever applicable,
  * 3 = 128-row kernels only and never the deep (4-stage) ring; + 16 = the serial per-pass residual read-out of rounds 1-4 in the
  * epilogue instead of round 5's grouped loads (bitwise the same results; A/B); bits 8..11 = nf in 5..8: pin the 8-phase kernel's
  * tile height to 32 nf rows (with variant 0 or 2; bitwise the same results). */

@@ -1159,7 +1159,8 @@ def test_conv2d_bf16x3_8phase_bit_identical(hip, B, H, W, Cin, Cout, k, stride, 
         # round 5's grouped-load epilogue (conv_x3_common.h) must reproduce bit for bit in every kernel
         # 2 | nf << 8: the 8-phase kernel pinned to tiles of 32 nf pixels (round 5: 160 / 192 / 224 rows; the second half of a wave's rows
         # has nf - 4 fragments, the epilogue's grouped loads cover 4 / 8 / 12 passes)
-        for variant in (19, 3, 1, 2, 0, 2 | (5 << 8), 2 | (6 << 8), 2 | (7 << 8)):
+        # 4: the 256 px x 128 cout two-resident-workgroups kernel (round 5) wherever Cout % 128 == 0
+        for variant in (19, 3, 1, 2, 0, 2 | (5 << 8), 2 | (6 << 8), 2 | (7 << 8), 4):
             lib.ufm_debug_set_conv_variant(variant)
             out = torch.full(oshape, 7.0, device=DEV, dtype=torch.bfloat16)
             orl = None if shuffle else torch.full(oshape, 7.0, device=DEV, dtype=torch.bfloat16)
@@ -1168,7 +1169,7 @@ def test_conv2d_bf16x3_8phase_bit_identical(hip, B, H, W, Cin, Cout, k, stride, 
             outs[variant] = (out.cpu(), None if shuffle else orl.cpu())
     finally:
         lib.ufm_debug_set_conv_variant(0)
-    for v in (3, 1, 2, 0, 2 | (5 << 8), 2 | (6 << 8), 2 | (7 << 8)):
+    for v in (3, 1, 2, 0, 2 | (5 << 8), 2 | (6 << 8), 2 | (7 << 8), 4):
         assert torch.equal(outs[19][0].view(torch.int16), outs[v][0].view(torch.int16)), v
         if not shuffle:
             assert torch.equal(outs[19][1].view(torch.int16), outs[v][1].view(torch.int16)), v

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ufm_amd import hip
 lib = hip.lib()
 B = 8
-shapes = [(296, 256, 128, 3, False, 0), (148, 256, 256, 3, True, 1), (74, 256, 256, 3, True, 1), (37, 256, 256, 3, True, 1), (296, 256, 256, 3, False, 0),
+shapes = [(296, 256, 128, 3, False, 0), (148, 256, 128, 3, False, 0), (296, 128, 128, 3, True, 1), (148, 256, 256, 3, True, 1), (74, 256, 256, 3, True, 1), (37, 256, 256, 3, True, 1), (296, 256, 256, 3, False, 0),
           (148, 192, 256, 3, False, 0), (74, 384, 256, 3, False, 0), (148, 96, 256, 1, False, 0)]
 for h, cin, cout, k, relu, nres in shapes:
     x = torch.randn(2, B, h, h, cin, device="cuda").bfloat16()
@@ -18,7 +18,7 @@ for h, cin, cout, k, relu, nres in shapes:
     fl = 2.0 * B * h * h * cout * k * k * cin
     def run():
         hip.conv2d_x3(x, B, h, h, cin, w, cout, k, k, 1, k // 2, out, zero, relu_in=relu, bias=bias, res1=r1 if nres else None)
-    times = {v: [] for v in (1, 2, 0)}
+    times = {v: [] for v in (1, 2, 4, 0)}
     for rnd in range(5):
         for v in times:
             lib.ufm_debug_set_conv_variant(v)

@@ -337,7 +337,13 @@ static void launch_conv_x3(const ConvX3Args& p_in, int passes, hipStream_t strea
     const int tile_n = 256, tile_m = 256;
     const bool ok8 = Cout % 256 == 0 && KH * KW * (Cin / 32) >= 2 && p.in_plane < (1ll << 31) && p.w_plane < (1ll << 31);
     const long long t8 = ((M + tile_m - 1) / tile_m) * (Cout / tile_n) * G;  // 8-phase tiles of all groups
-    if (passes == 1 || S > 1) {  // (split-K lives in the 128- / 64-row kernels: its layers are the small maps the 8-phase tile never fits)
+    // 256 px x 128 cout pair tile (round 5): Cout a multiple of 128 but not of 256 (the heads' p_conv1, 296^2 x 256 -> 128) on grids of at
+    // least one workgroup per CU.  g_conv_variant 4 = wherever it applies (tests), 1 / 3 = never.
+    const bool okp = Cout % 128 == 0 && KH * KW * (Cin / 32) >= 2 && p.in_plane < (1ll << 31) && p.w_plane < (1ll << 31) && passes == 3 && S == 1;
+    const long long tpair = ((M + 255) / 256) * (Cout / 128) * G;
+    if (okp && (g_conv_variant == 4 || (g_conv_variant == 0 && Cout % 256 != 0 && tpair >= ufm_device_cu_count() && KH * KW * (Cin / 32) >= 16))) {
+        ufm_launch_conv_x3_pair(p, stream);
+    } else if (passes == 1 || S > 1) {  // (split-K lives in the 128- / 64-row kernels: its layers are the small maps the 8-phase tile never fits)
         launch128(p);
     } else if (ok8 && g_conv_variant == 2) {
         ufm_launch_conv_x3_8ph(p, stream, nf_pin >= 5 && nf_pin <= 8 ? nf_pin : 8);
