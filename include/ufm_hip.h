@@ -143,7 +143,9 @@ int ufm_cross_attention_bf16x3(const uint16_t* q, int ldq, const uint16_t* k, co
  * tile_rows: 0 = cost model, 160 / 192 / 224 / 256 = pin the row height of the 8-phase tiles (results are bitwise the same).
  * Round 5: variant 6 = the 256x128 four-wave kernel with two resident workgroups per CU (gemm_bf16_pair.hip; any N % 128 == 0,
  * K >= 128; bitwise the other kernels); flags bits 16..22 = first-round start delay of a CU's second resident workgroup in
- * that kernel (units of s_sleep(64); results right). */
+ * that kernel (units of s_sleep(64); results right); variant 7 = the persistent 8-phase kernel (gemm_bf16_8ph_persist.hip) on every
+ * bf16-output launch of whole 256-row tiles with a compile-time epilogue (auto uses it on whole rounds of the chip only); flags bit 28 =
+ * never the persistent kernel in auto. */
 int ufm_debug_set_gemm_variant(int variant);
 int ufm_debug_set_gemm_flags(int flags);
 int ufm_debug_set_gemm_tile_rows(int rows);

@@ -161,6 +161,37 @@ def test_gemm_8phase_bitwise_equals_128_kernel_repeated(hip, M, N, K):
         lib.ufm_debug_set_gemm_flags(0)
 
 
+@pytest.mark.parametrize("M,N,K", [(256 * 9, 1024, 128), (256 * 40, 2048, 192), (256 * 32, 4096, 1024), (256 * 86, 3072, 1024), (256 * 3, 256, 256), (256 * 65, 1024, 448)])
+def test_gemm_persistent_8phase_bitwise_equals_128_kernel_repeated(hip, M, N, K):
+    """gemm_bf16_8ph_persist.hip (round 5): one workgroup per CU walks tiles v, v + grid, ..., the next tile's prologue DMAs are issued in
+    front of the current tile's epilogue stores and the epilogue goes through a 4-KiB staging slice per wave.  Same K order and the same
+    operations per element as the other kernels: BIT-identical to the 128x128 kernel, for both bf16-output epilogues (bias + GELU, bias +
+    per-column scale), over repeated launches (a prefetch that lands in a buffer still being read, or a counted wait that a store of the
+    previous tile makes too weak, shows as a rare wrong tile), with 1 / 2 / 3+ tiles per workgroup, uneven tile counts (variant 7 runs the
+    kernel on any tile count) and whole rounds (the shapes the auto dispatch sends to it), K-tile counts 2, 3, 7, 16."""
+    lib = hip.lib()
+    A = bf16r(rnd(M, K, seed=1)).to(DEV).bfloat16()
+    W = bf16r(rnd(N, K, seed=2, scale=K**-0.5)).to(DEV).bfloat16()
+    bias, gamma = rnd(N, seed=3, scale=0.1).to(DEV), (1.0 + rnd(N, seed=7, scale=0.2)).to(DEV)
+    try:
+        lib.ufm_debug_set_gemm_variant(1)
+        want_b = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+        hip.gemm_bf16(A, W, M, N, K, want_b, bias=bias, act=1)
+        want_g = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+        hip.gemm_bf16(A, W, M, N, K, want_g, bias=bias, gamma=gamma)
+        for variant in (7, 0):
+            lib.ufm_debug_set_gemm_variant(variant)
+            for rep in range(3):
+                got_b = torch.full((M, N), 3.0, device=DEV, dtype=torch.bfloat16)
+                hip.gemm_bf16(A, W, M, N, K, got_b, bias=bias, act=1)
+                assert torch.equal(got_b.view(torch.int16), want_b.view(torch.int16)), (variant, rep, "bias + GELU")
+                got_g = torch.full((M, N), 3.0, device=DEV, dtype=torch.bfloat16)
+                hip.gemm_bf16(A, W, M, N, K, got_g, bias=bias, gamma=gamma)
+                assert torch.equal(got_g.view(torch.int16), want_g.view(torch.int16)), (variant, rep, "bias + scale")
+    finally:
+        lib.ufm_debug_set_gemm_variant(0)
+
+
 def test_gemm_8phase_tile_heights_with_row_tables(hip):
     """The row-remapped epilogue (residual table indexed modulo a period, output rows skipping one slot per group -- the
     patch-embed / view-embedding forms) under every 8-phase tile height: bitwise the 128x128 kernel's result."""

@@ -75,7 +75,7 @@ try:
 except Exception:
     has_gpu = False
 if not has_gpu:
-    for variant in (0, 1, 4, 5, 6):
+    for variant in (0, 1, 4, 5, 6, 7):
         lib.ufm_debug_set_gemm_variant(variant)
         for rows in (0, 160, 192, 224, 256):
             lib.ufm_debug_set_gemm_tile_rows(rows)

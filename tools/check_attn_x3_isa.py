@@ -6,15 +6,15 @@
     `s_waitcnt vmcnt(0)` in front of the barrier is the ONLY thing that orders them: hipcc must not have added loads of its own);
   * every kernel body is spill- and scratch-free and contains no compiler-inserted `s_waitcnt vmcnt` inside the loop's MFMA
     blocks (with the LDS-DMA builtin hipcc put a vmcnt(0) in front of slot Y's first ds_read: the tile just requested).
-Usage: check_attn_x3_isa.py <file.s>"""
+Usage: check_attn_x3_isa.py <file.s> [kernel name substring]   (also run on gemm_bf16_8ph_persist.hip, whose DMAs are asm too)"""
 import re
 import sys
 
 
-def main(path):
+def main(path, kernel="attn_x3_pw_kernel"):
     txt = open(path).read()
     bad, bodies = [], 0
-    for m in re.finditer(r"^(_ZN\S*attn_x3_pw_kernel\S*):[^\n]*\n(.*?)s_endpgm", txt, re.S | re.M):
+    for m in re.finditer(r"^(_ZN\S*" + kernel + r"\S*):[^\n]*\n(.*?)s_endpgm", txt, re.S | re.M):
         bodies += 1
         name, body = m.group(1), m.group(2)
         in_asm = False
@@ -50,7 +50,7 @@ def main(path):
         if n_dma == 0:
             bad.append((name, "no LDS-DMA found: is this the right file?"))
     if bodies == 0:
-        bad.append(("-", "no attn_x3_pw_kernel body found"))
+        bad.append(("-", f"no {kernel} body found"))
     for n, b in bad:
         print(f"check_attn_x3_isa: {n[:60]}: {b}")
     if bad:
@@ -59,4 +59,4 @@ def main(path):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], *sys.argv[2:3])

@@ -158,8 +158,8 @@ __global__ __launch_bounds__(256, KS == 1 ? 2 : 1) void gemm_bf16_kernel(GemmArg
 static int g_gemm_variant = 0;  // 0 auto, 1 = 128x128 kernel, 4 = 256x256 8-phase kernel, 5 = hybrid (8-phase on whole rounds + 128x128 on the rest)
 static int g_gemm_flags = 0;    // diagnostics (tools/): 2 = no DMA, 4 = no epilogue traffic, 8 = direct (un-staged) epilogue of the 128x128 kernel
 extern "C" int ufm_debug_set_gemm_variant(int variant) {
-    if (variant != 0 && variant != 1 && variant != 4 && variant != 5 && variant != 6) {
-        ufm_set_error("ufm_debug_set_gemm_variant: %d is not one of 0 (auto), 1 (128x128), 4 (8-phase), 5 (hybrid), 6 (256x128 pair)", variant);
+    if (variant != 0 && variant != 1 && variant != 4 && variant != 5 && variant != 6 && variant != 7) {
+        ufm_set_error("ufm_debug_set_gemm_variant: %d is not one of 0 (auto), 1 (128x128), 4 (8-phase), 5 (hybrid), 6 (256x128 pair), 7 (persistent 8-phase)", variant);
         return UFM_ERR_ARG;
     }
     g_gemm_variant = variant;
@@ -185,7 +185,7 @@ extern "C" int ufm_debug_set_gemm_stamps(unsigned long long* buf, int rows) {
     return UFM_OK;
 }
 extern "C" int ufm_debug_set_gemm_flags(int flags) {
-    g_gemm_flags = flags & (2 | 4 | 8 | 16 | 32 | 64 | 128 | 0xff00 | 0x7f0000 | 0x800000 | 0xf000000);  // 0xf000000: flip the four auto rules of the pair kernel (A/B)  // 0x800000: the serial read-modify-write read-out (A/B of round 5's pipelined one)  // 0x70000: start stagger of the 8-phase kernel's first round (lab)  // 128: never the two-K-tiles-per-barrier form of the 128x128 kernel  // 64: generic (run-time switched) epilogue in the 8-phase kernels  // 16 / 32: lda / ldw = 0 (every tile reads the same rows: an all-L2-hit probe, tools/lab)
+    g_gemm_flags = flags & (2 | 4 | 8 | 16 | 32 | 64 | 128 | 0xff00 | 0x7f0000 | 0x800000 | 0xf000000 | 0x10000000);  // 0x10000000: never the persistent 8-phase kernel (A/B)  // 0xf000000: flip the four auto rules of the pair kernel (A/B)  // 0x800000: the serial read-modify-write read-out (A/B of round 5's pipelined one)  // 0x70000: start stagger of the 8-phase kernel's first round (lab)  // 128: never the two-K-tiles-per-barrier form of the 128x128 kernel  // 64: generic (run-time switched) epilogue in the 8-phase kernels  // 16 / 32: lda / ldw = 0 (every tile reads the same rows: an all-L2-hit probe, tools/lab)
     return UFM_OK;
 }
 
@@ -321,14 +321,36 @@ extern "C" int ufm_gemm_bf16_rope(const uint16_t* A, int lda, const uint16_t* W,
     } else if (plain_rows && bias && out_dtype == UFM_F32 && res && act == UFM_ACT_NONE) {
         epi = gamma ? 3 : 4;
     }
+    // Persistent 8-phase form (round 5, gemm_bf16_8ph_persist.hip): bf16-output launches of WHOLE 256-row tiles that make whole rounds of the
+    // chip -- the lead part of the hybrid split, or a whole GEMM whose tile count is a multiple of the CU count.  Flag bit 28 = never (A/B).
+    auto persist_able = [&](const GemmArgs& q) {  // what the kernel needs: a bf16-output compile-time epilogue, whole 256-row tiles
+        const long long rows = q.M - q.m_begin;
+        return (epi == 1 || epi == 2) && out_dtype == UFM_BF16 && ok8 && rows > 0 && rows % 256 == 0 && !q.stamps && !(g_gemm_flags & (2 | 4 | 16 | 32 | 0xff00 | 0x70000));
+    };
+    auto persist_ok = [&](const GemmArgs& q) {    // where it is dispatched: at least two whole rounds of the chip, nothing left over
+        const long long tiles = ((q.M - q.m_begin) / 256) * ntn;
+        return persist_able(q) && tiles >= 2 * NCU && tiles % NCU == 0 && !(g_gemm_flags & (1 << 28));
+    };
+    if (variant == 7) {  // tests / tools: the persistent kernel wherever it can run at all (any tile count), else the 8-phase kernel
+        if (persist_able(p)) {
+            ufm_launch_gemm_8ph_persist(p, (hipStream_t)stream, epi, NCU);
+            UFM_CHECK_LAUNCH("ufm_gemm_bf16");
+            return UFM_OK;
+        }
+        variant = ok8 ? 4 : 1;
+    }
     if (variant == 5) {
         GemmArgs lead = p, rest = p;
         lead.M = m_split;
         rest.m_begin = m_split;
+        if (persist_ok(lead)) ufm_launch_gemm_8ph_persist(lead, (hipStream_t)stream, epi, NCU);
+        else
         ufm_launch_gemm_8ph(lead, out_dtype, (hipStream_t)stream, 8, epi);
         if (nf_rest) ufm_launch_gemm_8ph(rest, out_dtype, (hipStream_t)stream, nf_rest, epi);
         else launch128(rest);
     } else if (variant == 4) {
+        if (nf_lead == 8 && g_gemm_variant == 0 && persist_ok(p)) ufm_launch_gemm_8ph_persist(p, (hipStream_t)stream, epi, NCU);
+        else
         ufm_launch_gemm_8ph(p, out_dtype, (hipStream_t)stream, nf_lead, epi);
     } else if (variant == 6) {
         ufm_launch_gemm_pair(p, out_dtype, (hipStream_t)stream, nf_pair, epi);

@@ -287,5 +287,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // epi: EpiTraits code the host has verified against the argument block (0 = generic)
 // p.stamps != nullptr selects the stamped diagnostic instantiation where one exists (8-phase: nf 6 / 8 with epi 1 / 3; pair: epi 1 / 3)
 int ufm_launch_gemm_8ph(const GemmArgs& p, int out_dtype, hipStream_t stream, int nf = 8, int epi = 0);
+// gemm_bf16_8ph_persist.hip: the persistent form for bf16-output launches of whole tiles (epi 1 / 2), next tile's prologue under the epilogue
+int ufm_launch_gemm_8ph_persist(const GemmArgs& p, hipStream_t stream, int epi, int ncu);
 // gemm_bf16_pair.hip: 256x128 4-wave kernel, two resident workgroups per CU (N % 128 == 0, K >= 128, 32-bit operand offsets)
 int ufm_launch_gemm_pair(const GemmArgs& p, int out_dtype, hipStream_t stream, int nf = 8, int epi = 0);
