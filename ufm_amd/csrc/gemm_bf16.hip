@@ -327,9 +327,10 @@ extern "C" int ufm_gemm_bf16_rope(const uint16_t* A, int lda, const uint16_t* W,
         const long long rows = q.M - q.m_begin;
         return (epi == 1 || epi == 2) && out_dtype == UFM_BF16 && ok8 && rows > 0 && rows % 256 == 0 && !q.stamps && !(g_gemm_flags & (2 | 4 | 16 | 32 | 0xff00 | 0x70000));
     };
-    auto persist_ok = [&](const GemmArgs& q) {    // where it is dispatched: at least two whole rounds of the chip, nothing left over
+    auto persist_ok = [&](const GemmArgs& q) {    // where it is dispatched: at least two rounds of the chip, the last one (all but) full
         const long long tiles = ((q.M - q.m_begin) / 256) * ntn;
-        return persist_able(q) && tiles >= 2 * NCU && tiles % NCU == 0 && !(g_gemm_flags & (1 << 28));
+        const long long short_of = (NCU - tiles % NCU) % NCU;  // the hybrid split's lead part is whole rounds less at most ntn - 1 tiles (whole tile ROWS)
+        return persist_able(q) && tiles + short_of >= 2 * NCU && short_of < ntn && !(g_gemm_flags & (1 << 28));
     };
     if (variant == 7) {  // tests / tools: the persistent kernel wherever it can run at all (any tile count), else the 8-phase kernel
         if (persist_able(p)) {
