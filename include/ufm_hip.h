@@ -145,7 +145,9 @@ int ufm_cross_attention_bf16x3(const uint16_t* q, int ldq, const uint16_t* k, co
  * K >= 128; bitwise the other kernels); flags bits 16..22 = first-round start delay of a CU's second resident workgroup in
  * that kernel (units of s_sleep(64); results right); variant 7 = the persistent 8-phase kernel (gemm_bf16_8ph_persist.hip) on every
  * bf16-output launch of whole 256-row tiles with a compile-time epilogue (auto uses it on whole rounds of the chip only); flags bit 28 =
- * never the persistent kernel in auto. */
+ * never the persistent kernel in auto; flags bits 24..27 = flip the auto dispatch's four pair-kernel rules (bit 24: the K = 768 bf16-output
+ * shapes, 25: N = 768 read-modify-write, 26: the encoder's QKV below 16 000 rows -- these three ON by default --, 27: everywhere, off);
+ * flags bit 23 = the serial read-modify-write read-out of rounds 1-4 (results right). */
 int ufm_debug_set_gemm_variant(int variant);
 int ufm_debug_set_gemm_flags(int flags);
 int ufm_debug_set_gemm_tile_rows(int rows);

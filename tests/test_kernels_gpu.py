@@ -161,6 +161,41 @@ def test_gemm_8phase_bitwise_equals_128_kernel_repeated(hip, M, N, K):
         lib.ufm_debug_set_gemm_flags(0)
 
 
+@pytest.mark.parametrize("M,N,K,mode", [(10952, 2304, 768, "scale"), (21904, 2304, 768, "scale"), (10952, 3072, 768, "gelu"), (10960, 3072, 1024, "scale"),
+                                         (21904, 768, 768, "rmw"), (10952, 768, 768, "rmw"), (21904, 768, 3072, "rmw"), (10952, 768, 3072, "rmw")])
+def test_gemm_auto_dispatch_on_the_pipeline_shapes_bitwise_equals_128_kernel(hip, M, N, K, mode):
+    """The auto dispatch at the shapes its per-shape rules name (the 256x128 two-resident-workgroups kernel on the D = 768 widths and on the
+    encoder's QKV at micro-batch rows, round 5; the hybrid / persistent forms elsewhere): whatever it picks is BIT-identical to the 128x128
+    kernel, with the rules on (default) and flipped (flag bits 24..27), for the three hot epilogues, ragged last tiles included."""
+    lib = hip.lib()
+    A = bf16r(rnd(M, K, seed=1)).to(DEV).bfloat16()
+    W = bf16r(rnd(N, K, seed=2, scale=K**-0.5)).to(DEV).bfloat16()
+    bias, gamma = rnd(N, seed=3, scale=0.1).to(DEV), (1.0 + rnd(N, seed=7, scale=0.2)).to(DEV)
+    res0 = rnd(M, N, seed=9).to(DEV)
+
+    def run():
+        if mode == "rmw":
+            out = res0.clone()
+            hip.gemm_bf16(A, W, M, N, K, out, bias=bias, gamma=gamma, res=out)
+        else:
+            out = torch.full((M, N), 3.0, device=DEV, dtype=torch.bfloat16)
+            hip.gemm_bf16(A, W, M, N, K, out, bias=bias, act=1 if mode == "gelu" else 0, gamma=None if mode == "gelu" else gamma)
+        return out
+
+    try:
+        lib.ufm_debug_set_gemm_variant(1)
+        want = run()
+        lib.ufm_debug_set_gemm_variant(0)
+        for flags in (0, 15 << 24, 8 << 24):
+            lib.ufm_debug_set_gemm_flags(flags)
+            for rep in range(2):
+                got = run()
+                assert torch.equal(got.view(torch.uint8), want.view(torch.uint8)), (flags, rep)
+    finally:
+        lib.ufm_debug_set_gemm_variant(0)
+        lib.ufm_debug_set_gemm_flags(0)
+
+
 @pytest.mark.parametrize("M,N,K", [(256 * 9, 1024, 128), (256 * 40, 2048, 192), (256 * 32, 4096, 1024), (256 * 86, 3072, 1024), (256 * 3, 256, 256), (256 * 65, 1024, 448)])
 def test_gemm_persistent_8phase_bitwise_equals_128_kernel_repeated(hip, M, N, K):
     """gemm_bf16_8ph_persist.hip (round 5): one workgroup per CU walks tiles v, v + grid, ..., the next tile's prologue DMAs are issued in

@@ -9,6 +9,9 @@ lib = hip.lib()
 B = 8
 SHAPES = [(148, 256, 256, 3, 1), (74, 256, 256, 3, 1), (148, 96, 256, 3, 0), (74, 192, 256, 3, 0), (37, 256, 256, 3, 1)]
 VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "0,2").split(",")]
+if os.environ.get("ABLATE"):  # timing ablations of the stamped instantiation (conv variant bits 12..17: 1 no LDS-DMA, 2 no fragment reads, 4 no MFMA, 8 no slot barriers, 16 nothing removed, 32 one rendezvous per phase)
+    VARIANTS = [2 | (int(a) << 12) for a in os.environ["ABLATE"].split(",")]
+    SHAPES = [(148, 256, 256, 3, 1), (148, 1024, 256, 1, 0), (148, 96, 256, 3, 0)]
 for h, cin, cout, k, nres in SHAPES:
     x = torch.randn(2, B, h, h, cin, device="cuda").bfloat16(); x[1] *= 2.0 ** -9
     w = (torch.randn(2, cout, k, k, cin, device="cuda") * (cin * k * k) ** -0.5).bfloat16(); w[1] *= 2.0 ** -9

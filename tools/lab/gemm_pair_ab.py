@@ -45,6 +45,8 @@ for _one in (0,):
         arms += [(f"pair r{r}", 6, 0, int(r)) for r in os.environ.get("ROWS", "").split(",") if r]
         if os.environ.get("PERSIST") and mode != "res":  # auto with / without the persistent 8-phase kernel (flag bit 28 = never)
             arms = [("auto", 0, 0, 0), ("auto, no persistent", 0, 1 << 28, 0)]
+        if os.environ.get("STAG8"):  # first-round start stagger of the 8-phase kernel (flag bits 16..18: (block / 8) % 4 x units x ~1 us)
+            arms = [("8-phase", 0, 0, 0)] + [(f"8-phase stagger {u}", 0, int(u) << 16, 0) for u in os.environ["STAG8"].split(",")]
         if os.environ.get("OLD_EPI") and mode == "res":  # the serial read-modify-write read-out of rounds 1-4 (flag 0x800000)
             arms += [("auto old-epi", 0, 0x800000, 0), ("pair old-epi", 6, 0x800000, 0)]
         lib.ufm_debug_set_gemm_variant(1); lib.ufm_debug_set_gemm_flags(0); lib.ufm_debug_set_gemm_tile_rows(0)

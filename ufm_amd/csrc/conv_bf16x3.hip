@@ -256,7 +256,8 @@ extern "C" int ufm_debug_set_conv_stamps(unsigned long long* buf, int rows) {
 }
 static int g_conv_variant_all = 0;
 // test/tuning hook: 0 = auto, 1 = 128-row kernels only, 2 = 8-phase kernel wherever it is applicable,
-// 3 = 128-row kernels only and never the deep (NS = 4) ring; + 16 = the serial (per-pass) residual read-out of rounds 1-4
+// 3 = 128-row kernels only and never the deep (NS = 4) ring; + 16 = the serial (per-pass) residual read-out of rounds 1-4;
+// bits 8..11 = pinned 8-phase tile height; bits 12..18 (with stamps set) = timing ablations of the 8-phase loop (ConvX3Args::ablate)
 extern "C" int ufm_debug_set_conv_variant(int v) {
     g_conv_variant_all = v;
     return UFM_OK;
@@ -291,6 +292,7 @@ static void launch_conv_x3(const ConvX3Args& p_in, int passes, hipStream_t strea
     ConvX3Args p = p_in;
     p.serial_epilogue = (g_conv_variant_all >> 4) & 1;
     p.stamps = g_conv_stamps, p.stamp_rows = g_conv_stamp_rows;
+    p.ablate = g_conv_stamps ? (g_conv_variant_all >> 12) & 127 : 0;  // (only the stamped instantiation reads it)
     const int nf_pin = (g_conv_variant_all >> 8) & 15;  // tools / tests: pin the 8-phase tile height (5..8 fragments per wave row)
     const int g_conv_variant = g_conv_variant_all & 15;
     const int Cout = p.Cout, KH = p.KH, KW = p.KW, Cin = p.Cin;

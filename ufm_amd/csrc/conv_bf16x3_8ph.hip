@@ -37,7 +37,8 @@ struct TapIter {  // walks the K-tiles of one half-tile kind: channel-chunk oute
 // let the Linear layers of numerics "precise" (ufm_gemm_bf16x3: M = 21 920 rows x N = 1024 is 344 tiles of 256 rows on 256 CUs) fill
 // whole rounds of the chip.  (Round 5 also tried the phase's 24 MFMAs product-major over its eight accumulators instead of three
 // per accumulator back to back: neutral, 478.7 vs 479.2 us on the 148^2 layer, tools/lab/conv_stamps.py -- not kept.)
-template <int WR, int WC, bool STAMP = false, int NF = 8>
+// ABL: timing ablations of the loop (ConvX3Args::ablate; a diagnostic instantiation of its own, so that the stamped kernel stays the shipped loop)
+template <int WR, int WC, bool STAMP = false, int NF = 8, bool ABL = false>
 __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
     static_assert(WR * WC == 8, "eight waves");
     static_assert(NF >= 5 && NF <= 8 && (NF == 8 || WR == 2), "NF");
@@ -102,6 +103,14 @@ __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
         constexpr int H = KIND >> 1;
         TapIter& ti = it[KIND];
         char* base = smem + (tile & 1) * KTILE + half_off(KIND);
+        if constexpr (ABL) {
+            if (p.ablate & 1) return;  // timing ablation: no LDS-DMA (the counted waits fall through)
+            if ((p.ablate & 64) && (KIND & 1) && ti.tap != 0) {  // timing emulation of a halo tile: the X pieces of one tap in nine only
+                if (++ti.kw == p.KW) ti.kw = 0, ++ti.kh;
+                if (++ti.tap == ntaps) ti.tap = 0, ti.kh = 0, ti.kw = 0, ti.c0 += 32;
+                return;
+            }
+        }
         if (KIND & 1) {
 #pragma unroll
             for (int i = 0; i < XPR; ++i) {
@@ -152,6 +161,9 @@ __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
     bf16x8 xf[4][2], wa[2][2], wb[2][2];  // [frag][plane]
 
     auto read_x = [&](int tile, int mh) {
+        if constexpr (ABL) {
+            if (p.ablate & 2) return;  // timing ablation: no fragment reads
+        }
         const char* s = smem + (tile & 1) * KTILE + half_off(1 + 2 * mh);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -161,6 +173,9 @@ __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
         }
     };
     auto read_w = [&](bf16x8 (&w)[2][2], int tile, int nh) {
+        if constexpr (ABL) {
+            if (p.ablate & 2) return;
+        }
         const char* s = smem + (tile & 1) * KTILE + half_off(2 * nh);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -181,18 +196,22 @@ __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
             }
         }
         __builtin_amdgcn_s_setprio(1);
+        bool do_mfma = true, do_bar = true;
+        if constexpr (ABL) do_mfma = !(p.ablate & 4), do_bar = !(p.ablate & 8) && !((p.ablate & 32) && wr == 0);  // timing ablations; 32: one rendezvous per phase (group 0 keeps the l_end barriers, group 1 the mma barriers) -- NOT a legal schedule: a half-tile is read one phase after its landing wait, the mid-phase rendezvous is what publishes it
+        if (do_mfma) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int i = 0; i < (MH == 0 ? 4 : NF - 4); ++i) {
-                f32x4& a = acc[MH][NH * 2 + j][i];
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][1], xf[i][0], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][0], xf[i][1], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][0], xf[i][0], a, 0, 0, 0);
-            }
+                for (int i = 0; i < (MH == 0 ? 4 : NF - 4); ++i) {
+                    f32x4& a = acc[MH][NH * 2 + j][i];
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][1], xf[i][0], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][0], xf[i][1], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][0], xf[i][0], a, 0, 0, 0);
+                }
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        if (do_bar) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
     // end of the L slot of phase ph (= 4 * tile + i): issue half-tile ph + 6, wait for half-tile ph + 2, barrier
@@ -211,7 +230,9 @@ __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
             else wait_vmcnt<0>();
         }
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        bool do_bar = true;
+        if constexpr (ABL) do_bar = !(p.ablate & 8) && !((p.ablate & 32) && wr == 1);
+        if (do_bar) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
     auto tile_body = [&](int t, bf16x8 (&wcur)[2][2], bf16x8 (&wnxt)[2][2]) {  // wcur holds W-lo(t) on entry
@@ -270,7 +291,8 @@ int ufm_launch_conv_x3_8ph(const ConvX3Args& p, hipStream_t stream, int nf) {
     const int rows = 32 * nf;
     const int ntm = (p.M - p.m_begin + rows - 1) / rows * p.groups;
     const dim3 grid(ntm * (p.Cout / 256)), block(512);
-    if (p.stamps && nf == 8) hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4, true>), grid, block, 0, stream, p);  // diagnostic build
+    if (p.stamps && nf == 8 && p.ablate) hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4, true, 8, true>), grid, block, 0, stream, p);  // timing ablations
+    else if (p.stamps && nf == 8) hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4, true>), grid, block, 0, stream, p);  // diagnostic build
     else if (nf == 5) hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4, false, 5>), grid, block, 0, stream, p);
     else if (nf == 6) hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4, false, 6>), grid, block, 0, stream, p);
     else if (nf == 7) hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4, false, 7>), grid, block, 0, stream, p);

@@ -38,6 +38,7 @@ struct ConvX3Args {
     // diagnostic build only (ufm_debug_set_conv_stamps; the STAMP = true instantiation of the 8-phase kernel): 8 x uint64 per workgroup
     unsigned long long* stamps;
     int stamp_rows;
+    int ablate;  // diagnostic build only (ufm_debug_set_conv_variant bits 12..17): 1 no LDS-DMA, 2 no fragment reads, 4 no MFMA, 8 no slot barriers -- TIMING ONLY, results wrong; 16 nothing removed; 32 one rendezvous per phase (timing only: not a legal schedule); 64 the X pieces of one tap in nine (the DMA count of a halo tile)
 };
 
 // tile row index over all groups -> (group, tile row inside the group); tiles_pg = row tiles per group of this launch

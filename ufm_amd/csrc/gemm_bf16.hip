@@ -279,13 +279,14 @@ extern "C" int ufm_gemm_bf16_rope(const uint16_t* A, int lda, const uint16_t* W,
         nf_lead = g_gemm_tile_rows / 32;
     }
     if ((variant == 4 || variant == 5) && !ok8) variant = 1;
-    // The 256x128 two-resident-workgroups kernel (gemm_bf16_pair.hip) where it measured faster than the choice above, per shape and
-    // row count, isolated launches behind a cold cache (tools/lab/gemm_pair_ab.py, profiles/r05/gemm_pair_ab.log) and in the
-    // two-stream pipeline (profiles/r05/gemm_pair_pipeline_ab.log): the info-sharing widths (D = 768: three or nine 256-column tiles
-    // quantise badly on 256 CUs) and the encoder's QKV at micro-batch row counts.  Flag bits 24..27 flip the four rules (A/B).
+    // The 256x128 two-resident-workgroups kernel (gemm_bf16_pair.hip) on the shapes where it measured faster than the choice above, isolated behind a cold
+    // cache (tools/lab/gemm_pair_ab.py, profiles/r05/gemm_pair_ab.log): the info-sharing widths (D = 768: three or nine 256-column tiles quantise badly on
+    // 256 CUs) and the encoder's QKV at micro-batch row counts.  In the two-stream pipeline the three rules together are worth +1.7 % pairs/s (35.49 vs
+    // 36.11 ms, 12 interleaved rounds; profiles/r05/gemm_pair_pipeline_ab.log -- the first pipeline A/B of round 5 called them neutral because its flagged
+    // arm also ran the 8-phase kernel column-major: the grouped-rasterization height read every flag bit above 8).  Flag bits 24..27 flip the rules (A/B).
     int nf_pair = g_gemm_tile_rows ? g_gemm_tile_rows / 32 : 8;
     if (g_gemm_variant == 0 && K >= 128 && fits32 && !g_gemm_tile_rows) {
-        constexpr int PAIR_DEFAULT = 0;
+        constexpr int PAIR_DEFAULT = 7;
         const int pol = PAIR_DEFAULT ^ ((g_gemm_flags >> 24) & 15);
         const bool small = M < 16000;
         int nfp = 0;

@@ -48,7 +48,9 @@ __device__ __forceinline__ void gemm_bf16_8ph_body(const GemmArgs& p, char* smem
     // ---- tile of this block: XCD chunking + grouped rasterization (as gemm_bf16.hip) ----
     const int ntn = p.N >> 8, ntm = (p.M - p.m_begin + BMT - 1) / BMT;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int GM = (p.debug >> 8) ? (p.debug >> 8) : 8;  // grouped rasterization height (tools/lab/gemm_gm_probe.py: flags >> 8); 8 vs 4: QKV -8 %, others +-1 %
+    // grouped rasterization height (tools/lab/gemm_gm_probe.py: flag bits 8..15); 8 vs 4: QKV -8 %, others +-1 %.  (Until late in round 5 this read ALL bits above 8: every A/B arm
+    // that set one of the later lab flags -- bits 16..28 -- also ran this kernel column-major, GM = 2^k; the affected logs say so.)
+    const int GM = ((p.debug >> 8) & 0xff) ? ((p.debug >> 8) & 0xff) : 8;
     const int per_group = GM * ntn;
     const int grp = bid / per_group, in_g = bid - grp * per_group;
     const int gm = min(GM, ntm - grp * GM);
