@@ -135,6 +135,13 @@ int ufm_cross_attention_f32(const float* q, int ldq, const float* k, const float
 int ufm_cross_attention_bf16x3(const uint16_t* q, int ldq, const uint16_t* k, const uint16_t* v, int ldkv, uint16_t* out, int ldo,
                                int B, int Nq, int Nk, int H, float scale, void* stream);
 
+/* Launch objective of the tile-height choice in ufm_gemm_bf16 / ufm_gemm_bf16x3 / ufm_conv2d_nhwc_bf16x3 (round 5).  By default a launch is
+ * dispatched as if it ran alone on the chip (lowest latency).  A caller that drives SEVERAL streams concurrently -- the engine's two micro-batch
+ * streams, the way the reference's users run independent pair batches side by side -- flags those streams once: launches on a flagged stream of
+ * 8192 rows or more then use full-height 8-phase tiles only (fewer, more efficient workgroups: less CU time taken from the neighbour stream;
+ * +1...+2.4 % pairs/s "fast", +2.2...+2.8 % "precise" in the two-stream pipeline, -0.8 % if the stream in fact runs alone).  Results are bitwise
+ * the same either way.  on = 0 removes the flag.  At most 32 streams; the null stream cannot be flagged.  Thread-safe. */
+int ufm_hint_concurrent_stream(void* stream, int on);
 /* Tuning hooks (tests / tools only; the product path never calls them).
  * variant: 0 = auto (cost model per shape), 1 = 128x128 kernel, 4 = 256x256 8-phase kernel, 5 = hybrid (8-phase on the rows
  * that fill whole rounds of the chip + 128x128 on the rest).  flags (timing diagnostics, results are wrong): 2 = no DMA,
@@ -147,7 +154,8 @@ int ufm_cross_attention_bf16x3(const uint16_t* q, int ldq, const uint16_t* k, co
  * bf16-output launch of whole 256-row tiles with a compile-time epilogue (auto uses it on whole rounds of the chip only); flags bit 28 =
  * never the persistent kernel in auto; flags bits 24..27 = flip the auto dispatch's four pair-kernel rules (bit 24: the K = 768 bf16-output
  * shapes, 25: N = 768 read-modify-write, 26: the encoder's QKV below 16 000 rows -- these three ON by default --, 27: everywhere, off);
- * flags bit 23 = the serial read-modify-write read-out of rounds 1-4 (results right). */
+ * flags bit 23 = the serial read-modify-write read-out of rounds 1-4 (results right); flags bits 29 / 30 = the latency / the CU-time objective of
+ * the tile-height choice on every stream, whatever ufm_hint_concurrent_stream says. */
 int ufm_debug_set_gemm_variant(int variant);
 int ufm_debug_set_gemm_flags(int flags);
 int ufm_debug_set_gemm_tile_rows(int rows);

@@ -196,6 +196,42 @@ def test_gemm_auto_dispatch_on_the_pipeline_shapes_bitwise_equals_128_kernel(hip
         lib.ufm_debug_set_gemm_flags(0)
 
 
+def test_concurrent_stream_hint_changes_the_dispatch_not_the_bits(hip):
+    """ufm_hint_concurrent_stream (round 5): on a flagged stream launches of 8192 rows or more use full-height 8-phase tiles only (CU time
+    instead of latency as the objective).  Same arithmetic in the same order: the read-modify-write proj shape at micro-batch rows (172 tiles
+    of 256 rows flagged, 232 of 192 rows unflagged) and the bf16x3 Linear form give the same bits on a flagged and an unflagged stream; the
+    flag can be removed; the null stream is refused."""
+    lib = hip.lib()
+    M, N, K = 10960, 1024, 1024
+    A = bf16r(rnd(M, K, seed=1)).to(DEV).bfloat16()
+    W = bf16r(rnd(N, K, seed=2, scale=K**-0.5)).to(DEV).bfloat16()
+    bias, gamma = rnd(N, seed=3, scale=0.1).to(DEV), (1.0 + rnd(N, seed=7, scale=0.2)).to(DEV)
+    res0 = rnd(M, N, seed=9).to(DEV)
+    Ax = torch.stack([A, torch.zeros_like(A)]).contiguous()
+    Wx = torch.stack([W, torch.zeros_like(W)]).contiguous()
+    zero = torch.zeros(256, device=DEV)
+    side = torch.cuda.Stream()
+    assert lib.ufm_hint_concurrent_stream(None, 1) != 0
+    outs = {}
+    try:
+        for flagged in (False, True, False):
+            assert hip.hint_concurrent_stream(side, flagged)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                o = res0.clone()
+                hip.gemm_bf16(A, W, M, N, K, o, bias=bias, gamma=gamma, res=o)
+                o3 = res0.clone()
+                hip.gemm_x3(Ax, Wx, M, N, K, o3, zero, bias=bias, gamma=gamma, res=o3)
+            side.synchronize()
+            outs.setdefault(flagged, []).append((o, o3))
+    finally:
+        hip.hint_concurrent_stream(side, False)
+    (a, a3), (c, c3) = outs[False]
+    (b, b3), = outs[True]
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32)) and torch.equal(a.view(torch.int32), c.view(torch.int32))
+    assert torch.equal(a3.view(torch.int32), b3.view(torch.int32)) and torch.equal(a3.view(torch.int32), c3.view(torch.int32))
+
+
 @pytest.mark.parametrize("M,N,K", [(256 * 9, 1024, 128), (256 * 40, 2048, 192), (256 * 32, 4096, 1024), (256 * 86, 3072, 1024), (256 * 3, 256, 256), (256 * 65, 1024, 448)])
 def test_gemm_persistent_8phase_bitwise_equals_128_kernel_repeated(hip, M, N, K):
     """gemm_bf16_8ph_persist.hip (round 5): one workgroup per CU walks tiles v, v + grid, ..., the next tile's prologue DMAs are issued in

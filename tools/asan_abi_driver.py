@@ -63,6 +63,17 @@ expect((-1,), lib.ufm_debug_set_gemm_stamps(P, 0), "stamps buffer without rows")
 expect((0,), lib.ufm_debug_set_gemm_stamps(None, 0), "stamps off")
 expect((-1,), lib.ufm_debug_set_conv_stamps(None, 5), "conv stamps rows without buffer")
 expect((0,), lib.ufm_debug_set_conv_stamps(None, 0), "conv stamps off")
+# ufm_hint_concurrent_stream: a 32-entry table of opaque handles (no device call): null refused, flag / re-flag / remove, overflow reported
+lib.ufm_hint_concurrent_stream.argtypes = [C.c_void_p, C.c_int]
+lib.ufm_hint_concurrent_stream.restype = C.c_int
+expect((-1,), lib.ufm_hint_concurrent_stream(None, 1), "null stream cannot be flagged")
+for h in range(1, 33):
+    expect((0,), lib.ufm_hint_concurrent_stream(C.c_void_p(0x1000 * h), 1), "flag a stream")
+expect((0,), lib.ufm_hint_concurrent_stream(C.c_void_p(0x1000), 1), "flag it again")
+expect((-1,), lib.ufm_hint_concurrent_stream(C.c_void_p(0x999000), 1), "table full")
+for h in range(1, 33):
+    expect((0,), lib.ufm_hint_concurrent_stream(C.c_void_p(0x1000 * h), 0), "remove the flag")
+expect((0,), lib.ufm_hint_concurrent_stream(C.c_void_p(0x999000), 0), "removing an unknown stream is not an error")
 expect((-1,), lib.ufm_gather_rows_f32(P, 62, P, 4, 64, P, 64, None), "gather ld")
 expect((-1,), lib.ufm_debug_set_gemm_variant(3), "variant")
 expect((-1,), lib.ufm_debug_set_gemm_tile_rows(100), "tile rows")

@@ -36,6 +36,7 @@ void ufm_set_error(const char* fmt, ...);
 
 // Compute units of the CURRENT device (cached per device id): sizes persistent grids and the whole-rounds dispatch.
 int ufm_device_cu_count();
+bool ufm_stream_is_concurrent(void* stream);  // error.cpp: flagged by ufm_hint_concurrent_stream
 
 // ---- bf16 <-> f32 (RNE; plain casts so NaN stays NaN, MI355X_MICROARCH "Correctness boundaries") ----
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((unsigned)h) << 16); }

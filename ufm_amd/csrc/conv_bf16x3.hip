@@ -257,7 +257,7 @@ extern "C" int ufm_debug_set_conv_stamps(unsigned long long* buf, int rows) {
 static int g_conv_variant_all = 0;
 // test/tuning hook: 0 = auto, 1 = 128-row kernels only, 2 = 8-phase kernel wherever it is applicable,
 // 3 = 128-row kernels only and never the deep (NS = 4) ring; + 16 = the serial (per-pass) residual read-out of rounds 1-4;
-// bits 8..11 = pinned 8-phase tile height; bits 12..18 (with stamps set) = timing ablations of the 8-phase loop (ConvX3Args::ablate); bit 19 = the latency cost model (lower tiles, hybrid split) at every row count
+// bits 8..11 = pinned 8-phase tile height; bits 12..18 (with stamps set) = timing ablations of the 8-phase loop (ConvX3Args::ablate); bits 19 / 20 = the latency / the CU-time objective of the tile-height choice on every stream (default: by ufm_hint_concurrent_stream)
 extern "C" int ufm_debug_set_conv_variant(int v) {
     g_conv_variant_all = v;
     return UFM_OK;
@@ -363,11 +363,12 @@ static void launch_conv_x3(const ConvX3Args& p_in, int passes, hipStream_t strea
         // (256-row tiles on the whole rounds + the 128-row kernels on a last partial round below half the chip) costs its whole rounds
         // + 0.6 .. 0.95 for the second launch.  M = 10 960 x N = 1024: 172 tiles of 256 rows (two thirds of a round) -> 232 of 192 rows,
         // 71.8 -> 67.5 us; x 768: 129 tiles -> 207 of 160 rows, 54.4 -> 48.0 us; the N >= 3072 shapes keep the hybrid form.
-        // That cost model prices one launch ALONE on the chip.  At multi-pair row counts the engine runs two micro-batch streams (and two head
-        // streams), and what counts is the CU time a launch takes from the other stream's kernels: lower tiles and the 128-row rest launch finish
-        // a lone launch sooner and cost more CU time.  From 8192 rows on: full-height tiles, no hybrid split -- numerics "precise" +2.2 % pairs/s
-        // (71.23 vs 72.77 ms), "fast" +0.2 % (profiles/r05/gemm_tile_policy_pipeline.log).  Variant bit 19 (lab): the latency model everywhere.
-        const bool only8 = M >= 8192 && !((g_conv_variant_all >> 19) & 1);
+        // That cost model prices one launch ALONE on the chip.  On a stream flagged by ufm_hint_concurrent_stream (the engine's micro-batch streams)
+        // what counts is the CU time a launch takes from the other stream's kernels: lower tiles and the 128-row rest launch finish a lone launch
+        // sooner and cost more CU time.  There, from 8192 rows on: full-height tiles, no hybrid split -- numerics "precise" +2.2...+2.8 % pairs/s,
+        // "fast" +-0 (profiles/r05/gemm_tile_policy_pipeline.log).  Variant bits 19 / 20 (lab): the latency / the CU-time objective on every stream.
+        const bool throughput = ((g_conv_variant_all >> 20) & 1) || (ufm_stream_is_concurrent(stream) && !((g_conv_variant_all >> 19) & 1));
+        const bool only8 = M >= 8192 && throughput;
         constexpr double FIX = 0.65;
         double best = 1e30;
         int best_nf = 8;

@@ -35,3 +35,34 @@ int ufm_device_cu_count() {
     }
     return n;
 }
+
+// Streams the caller has declared to run CONCURRENTLY with others of its own (ufm_hint_concurrent_stream): the tile-height choice of the
+// GEMM / bf16x3 dispatch then minimises the CU time a launch takes from its neighbours instead of its own latency.  A small fixed table,
+// written rarely (an engine flags its micro-batch streams when it creates them), read on every GEMM / convolution launch.
+static std::atomic<void*> g_conc_streams[32];
+extern "C" int ufm_hint_concurrent_stream(void* stream, int on) {
+    if (stream == nullptr) {
+        ufm_set_error("ufm_hint_concurrent_stream: the null (legacy default) stream cannot be flagged");
+        return UFM_ERR_ARG;
+    }
+    for (auto& e : g_conc_streams) {  // already there?
+        void* cur = e.load(std::memory_order_acquire);
+        if (cur == stream) {
+            if (!on) e.store(nullptr, std::memory_order_release);
+            return UFM_OK;
+        }
+    }
+    if (!on) return UFM_OK;
+    for (auto& e : g_conc_streams) {
+        void* expect = nullptr;
+        if (e.compare_exchange_strong(expect, stream, std::memory_order_acq_rel)) return UFM_OK;
+    }
+    ufm_set_error("ufm_hint_concurrent_stream: more than %d streams flagged", (int)(sizeof(g_conc_streams) / sizeof(g_conc_streams[0])));
+    return UFM_ERR_ARG;
+}
+bool ufm_stream_is_concurrent(void* stream) {
+    if (stream == nullptr) return false;
+    for (auto& e : g_conc_streams)
+        if (e.load(std::memory_order_relaxed) == stream) return true;
+    return false;
+}

@@ -185,7 +185,7 @@ extern "C" int ufm_debug_set_gemm_stamps(unsigned long long* buf, int rows) {
     return UFM_OK;
 }
 extern "C" int ufm_debug_set_gemm_flags(int flags) {
-    g_gemm_flags = flags & (2 | 4 | 8 | 16 | 32 | 64 | 128 | 0xff00 | 0x7f0000 | 0x800000 | 0xf000000 | 0x10000000 | 0x20000000 | 0x40000000);  // 0x20000000 / 0x40000000 (lab): lower 8-phase tiles also from 8192 rows on (the latency cost model) / never the hybrid split  // 0x10000000: never the persistent 8-phase kernel (A/B)  // 0xf000000: flip the four auto rules of the pair kernel (A/B)  // 0x800000: the serial read-modify-write read-out (A/B of round 5's pipelined one)  // 0x70000: start stagger of the 8-phase kernel's first round (lab)  // 128: never the two-K-tiles-per-barrier form of the 128x128 kernel  // 64: generic (run-time switched) epilogue in the 8-phase kernels  // 16 / 32: lda / ldw = 0 (every tile reads the same rows: an all-L2-hit probe, tools/lab)
+    g_gemm_flags = flags & (2 | 4 | 8 | 16 | 32 | 64 | 128 | 0xff00 | 0x7f0000 | 0x800000 | 0xf000000 | 0x10000000 | 0x20000000 | 0x40000000);  // 0x20000000 / 0x40000000 (lab): the latency / the CU-time objective of the tile-height choice on every stream (default: by ufm_hint_concurrent_stream)  // 0x10000000: never the persistent 8-phase kernel (A/B)  // 0xf000000: flip the four auto rules of the pair kernel (A/B)  // 0x800000: the serial read-modify-write read-out (A/B of round 5's pipelined one)  // 0x70000: start stagger of the 8-phase kernel's first round (lab)  // 128: never the two-K-tiles-per-barrier form of the 128x128 kernel  // 64: generic (run-time switched) epilogue in the 8-phase kernels  // 16 / 32: lda / ldw = 0 (every tile reads the same rows: an all-L2-hit probe, tools/lab)
     return UFM_OK;
 }
 
@@ -249,11 +249,13 @@ extern "C" int ufm_gemm_bf16_rope(const uint16_t* A, int lda, const uint16_t* W,
     };
     auto best8 = [&](int rows, int& nf_out) {  // cheapest tile height for `rows` rows
         double best = 1e30;
-        // The cost model prices ONE launch alone on the chip (its latency).  At the row counts of a multi-pair batch the engine runs two micro-batch
-        // streams and what counts is the CU time a launch consumes: 232 tiles of 192 rows finish a lone proj 7 % sooner than 172 tiles of 256 rows,
-        // but occupy 25 % more CU time that the other stream's kernels could have used.  From 8192 rows on only full-height tiles are considered:
-        // +1.0...+2.4 % pairs/s in the pipeline (profiles/r05/gemm_tile_policy_pipeline.log).  Flag bit 29 (lab): the cost model at every row count.
-        const bool only8 = rows >= 8192 && !(g_gemm_flags & (1 << 29));
+        // The cost model prices ONE launch alone on the chip (its latency).  On a stream the caller has flagged as one of several concurrent ones
+        // (ufm_hint_concurrent_stream: the engine's micro-batch streams) what counts is the CU time a launch consumes: 232 tiles of 192 rows finish
+        // a lone proj 7 % sooner than 172 tiles of 256 rows, but occupy 25 % more CU time that the other stream's kernels could have used.  There,
+        // from 8192 rows on, only full-height tiles are considered: +1.0...+2.4 % pairs/s in the pipeline, -0.8 % on a single stream -- hence the
+        // hint (profiles/r05/gemm_tile_policy_pipeline.log).  Flag bits 29 / 30 (lab): the latency / the CU-time objective on every stream.
+        const bool throughput = ((g_gemm_flags >> 30) & 1) || (ufm_stream_is_concurrent(stream) && !((g_gemm_flags >> 29) & 1));
+        const bool only8 = rows >= 8192 && throughput;
         for (int nf = 8; nf >= 5; --nf) {
             if (g_gemm_tile_rows && 32 * nf != g_gemm_tile_rows) continue;
             if (only8 && !g_gemm_tile_rows && nf != 8) continue;
@@ -273,7 +275,7 @@ extern "C" int ufm_gemm_bf16_rope(const uint16_t* A, int lda, const uint16_t* W,
             if (c4 < best) best = c4, best_variant = 4, nf_lead = nf;
             const int full = (int)(((long long)((M + 255) / 256) * ntn) / NCU);  // whole rounds of 256-row tiles
             const int rows_main = full * NCU / ntn * 256;                         // leading rows whose tiles fit in them
-            if (full > 0 && rows_main < M && !g_gemm_tile_rows && !(g_gemm_flags & (1 << 30))) {  // (flag bit 30, lab: never the hybrid split)
+            if (full > 0 && rows_main < M && !g_gemm_tile_rows) {
                 int nfr = 8;
                 const double r8 = best8(M - rows_main, nfr), r1 = rounds1(M - rows_main);
                 const double c5 = 0.08 + 0.92 * full + (r8 < r1 ? r8 : r1) + 0.3;

@@ -1034,6 +1034,7 @@ class Engine:
                 self._view_major_tables(bounds[i + 1] - bounds[i], gh * gw)
         while len(self._streams) < nmb:
             self._streams.append(torch.cuda.Stream(device=self.dev))
+            hip.hint_concurrent_stream(self._streams[-1])  # micro-batch streams run side by side: tile heights for CU time, not latency (include/ufm_hip.h)
         cur = torch.cuda.current_stream(self.dev)
         results: List[Any] = [None] * nmb
         errors: List[BaseException] = []

@@ -37,6 +37,7 @@ SIGNATURES = {
     "ufm_attention_bf16_strided": [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "ufm_cross_attention_f32": [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp],
     "ufm_cross_attention_bf16x3": [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp],
+    "ufm_hint_concurrent_stream": [_vp, _i],
     "ufm_debug_set_gemm_variant": [_i],
     "ufm_debug_set_gemm_flags": [_i],
     "ufm_debug_set_gemm_tile_rows": [_i],
@@ -200,6 +201,12 @@ def resize_antialias(img: torch.Tensor, layout: int, B: int, H: int, W: int, sca
     in_dtype = 0 if img.dtype == torch.uint8 else 1
     assert img.is_contiguous() and tmp.numel() >= B * 3 * H * Wo
     _check(lib().ufm_resize_antialias(_p(img), in_dtype, layout, B, H, W, _f3(scale3), _f3(shift3), _p(out), Ho, Wo, _p(tmp), _stream()), "ufm_resize_antialias")
+
+
+def hint_concurrent_stream(stream: "torch.cuda.Stream", on: bool = True) -> bool:
+    """Tell the library that ``stream`` runs side by side with other streams of the caller (ufm_hint_concurrent_stream): launches on it then
+    choose tile heights for CU time, not for their own latency.  A hint: returns False instead of raising when the table is full."""
+    return lib().ufm_hint_concurrent_stream(C.c_void_p(stream.cuda_stream), 1 if on else 0) == 0
 
 
 def gemm_bf16(A, W, M, N, K, out, *, bias=None, act=ACT_NONE, gamma=None, res=None, ldres=0, res_row_mod=0, lda=None, ldw=None, ldo=None, out_row_group=0, rope=None):
