@@ -136,12 +136,19 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_8ph_persist_kernel(GemmArgs 
     // gemm_bf16_8ph.hip: stores of the previous output tile's epilogue that are still in flight are YOUNGER than every half-tile a wait of the
     // first phases is for and OLDER than the DMAs issued here, so they can only make a wait stricter.
     const int nhalf = 4 * nt;
+    bool stores_behind = false;  // wave-uniform: the previous output tile's 16 stores may be in flight (always exactly 16 per wave: no ragged rows)
     auto l_end = [&](int tile, auto i_) {
         constexpr int I = decltype(i_)::value;
         const int ph = 4 * tile + I;
         if (ph + 6 < nhalf) {
             stage(IC<(I + 2) & 3>{}, tile + (I + 6) / 4);
-            wait_vmcnt<8>();
+            // K-tile 0 of an output tile that follows another one: this wave's 16 row stores of the previous epilogue sit, in issue order, between the
+            // prologue's half-tiles and the DMAs issued from here on.  vmcnt(8) would also wait for all but 8 - 2 (I + 1) of those stores -- the drain the
+            // prefetch was meant to overlap.  vmcnt(8 + 16) asks for exactly the half-tile this phase needs: with every store still in flight the 24
+            // youngest operations are the 8 - 2 (I + 1) remaining prologue pieces, the 16 stores and the 2 (I + 1) pieces issued since; with some stores
+            // retired (in issue order: everything older has retired with them) the wait can only be stricter than needed.
+            if (tile == 0 && stores_behind) wait_vmcnt<24>();
+            else wait_vmcnt<8>();
         } else {
             const int inflight = nhalf - ph - 3;
             if (inflight >= 3) wait_vmcnt<6>();
@@ -180,7 +187,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_8ph_persist_kernel(GemmArgs 
             for (int n = 0; n < 4; ++n)
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc[h][n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-        wait_vmcnt<8>();  // half-tiles 0 (W-lo) and 1 (X-lo) of this tile's K-tile 0 have landed (any stores of the previous epilogue: younger)
+        // half-tiles 0 (W-lo) and 1 (X-lo) of this tile's K-tile 0 have landed; behind an epilogue the 16 stores are younger than all 12 prologue pieces
+        if (stores_behind) wait_vmcnt<24>();
+        else wait_vmcnt<8>();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -249,6 +258,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_8ph_persist_kernel(GemmArgs 
             }
         if (!more) break;
         v = vn;
+        stores_behind = true;
     }
 }
 
