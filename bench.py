@@ -592,6 +592,8 @@ def main():
             "kernel": dom, "bound": "mfma", "achieved": d["achieved"], "peak": d["peak"], "unit": "TFLOP/s", "frac": d["frac"],
             "traffic": d.get("traffic"), "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
             "avg_launch_us": d["avg_launch_us"], "algorithmic_gflop_per_launch": d["algorithmic_gflop"] / d["launches"],
+            "measured_on": "three single-stream instrumented steps (HIP events around every launch, on the launch stream), per-launch medians; launches on a stream the "
+                           "engine has not flagged with ufm_hint_concurrent_stream are dispatched for their own latency, the timed two-stream steps for CU time",
         }
         attn_name = next((k for k in ("ufm_attention_bf16", "ufm_attention_bf16x3", "ufm_attention_f32") if k in kernels), None)
         if attn_name:
