@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: image-pairs/sec + p50 latency, UFM-Base 518x518, N x MI355X (BASELINE.json).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without WORLD_SIZE: starts the line below itself, as a child process)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -346,6 +346,39 @@ def p50_ms(fn, iters: int, warm: int) -> float:
     return sorted(ts)[len(ts) // 2]
 
 
+def launch_command(n_gpus: int, argv, port: int):
+    """The driver's own N > 1 command line: one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n_gpus: int, argv) -> int:
+    """`python bench.py --gpus N` (N > 1) started without a launcher: run the ranks as a child `torch.distributed.run`, relay
+    rank 0's single JSON line (stdout) and the ranks' stderr, return the child's exit code.  The parent makes no HIP call at all
+    (a process that has initialised the GPU must neither exec nor fork workers on this pool): it only imports torch."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "2")  # the launcher would set 1; every rank runs two launch threads
+    cmd = launch_command(n_gpus, argv, port)
+    print(f"[bench launcher] --gpus {n_gpus} without WORLD_SIZE: starting {' '.join(cmd[1:8])} ... as a child process", file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, cwd=ROOT)
+    lines = 0
+    for ln in proc.stdout:  # relay as it comes: exactly what the ranks print (rank 0's ONE JSON line)
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+        lines += ln.startswith("{")
+    rc = proc.wait()
+    print(f"[bench launcher] child exit code {rc}, JSON lines relayed {lines}, parent touched the GPU: {torch.cuda.is_initialized()}",
+          file=sys.stderr, flush=True)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -373,6 +406,11 @@ def main():
     ap.add_argument("--last-layer-view1", type=int, default=1, help="0: the last joint-attention block on all rows (A/B of Engine.last_layer_view1)")
     ap.add_argument("--micro-batches", type=int, default=2, help="concurrent micro-batches (HIP streams) per GPU; 1 = single stream")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the ranks ourselves (as a CHILD process -- this parent never
+        # touches the GPU) and leave with the launcher's return code
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

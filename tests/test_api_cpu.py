@@ -245,3 +245,61 @@ def test_param_epoch_moves_on_every_kind_of_registration():
     e = engine.PARAM_EPOCH[0]
     seq[0].bias = torch.nn.Parameter(torch.zeros(2))
     assert engine.PARAM_EPOCH[0] > e
+
+
+def test_bench_gpus_n_without_a_launcher_starts_its_own_ranks_and_never_touches_the_gpu(monkeypatch, capsys):
+    """`python bench.py --gpus N` (N > 1, WORLD_SIZE unset) used to die on an assertion.  The parent now
+    starts the driver's own command (torch.distributed.run, one process per GPU, 127.0.0.1) as a CHILD process, relays its
+    stdout, returns its exit code and makes no GPU call itself.  Partition: /root/reference/uniflowmatch/models/ufm.py:306-318
+    only ever cats / chunks on dim 0, so ranks split the pair batch."""
+    import os
+    import subprocess
+    import sys
+
+    import torch
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    cmd = bench.launch_command(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"], 29400)
+    assert cmd[:9] == [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1", "--master-port", "29400"]
+    assert cmd[9] == os.path.join(root, "bench.py") and cmd[10:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+
+    seen = {}
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, **kw):
+            seen["cmd"], seen["env"] = cmd, env
+            self.stdout = iter(['{"metric": "x", "n_gpus": 2}\n'])
+
+        def wait(self):
+            return 7
+
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    rc = bench.self_launch(2, ["--gpus", "2", "--steps", "1"])
+    out = capsys.readouterr()
+    assert rc == 7 and out.out == '{"metric": "x", "n_gpus": 2}\n'
+    assert "--nproc-per-node=2" in seen["cmd"] and seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert "parent touched the GPU: False" in out.err and not torch.cuda.is_initialized()
+
+
+def test_bench_gpus_2_end_to_end_on_a_box_without_a_gpu_fails_in_the_ranks_not_in_the_parent():
+    """The real thing here (no GPU): the parent launches two ranks, each rank refuses to run without an MI355X, the launcher's
+    non-zero exit code comes back as the parent's, and the parent reports that it never initialised the GPU."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    envv = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=600, env=envv, cwd=root)
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the two ranks would run the real benchmark (covered by the -m gpu rehearsal test)")
+    assert r.returncode != 0
+    assert "bench.py needs an MI355X" in r.stderr and "launch with torch.distributed.run" not in r.stderr
+    assert "parent touched the GPU: False" in r.stderr

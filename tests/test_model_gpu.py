@@ -878,6 +878,30 @@ def test_bench_two_ranks_sharing_the_gpu_gather_and_cross_check_each_other():
     assert line["summary"]["gather_check"]["bitwise_equal_to_local_recompute"] is True
 
 
+def test_bench_gpus_2_without_a_launcher_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2 ...` exactly as the driver starts `--gpus 1` -- no torch.distributed.run in
+    front, WORLD_SIZE unset.  The parent starts the ranks as a child process (bench.self_launch), relays rank 0's single JSON line
+    and exits with the child's code.  Same shared-GPU gloo rehearsal as the test above; a functional check, not a measurement."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    envv = dict(os.environ, UFM_BENCH_SHARE_GPU="1", UFM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "UFM_BENCH_FORCE_DIST", "MASTER_PORT", "MASTER_ADDR"):
+        envv.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2",
+                        "--no-cpu-baseline", "--no-parity-mode", "--no-precise-mode", "--no-latency", "--no-kernel-timing"],
+                       capture_output=True, text=True, timeout=900, env=envv, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # ONE JSON line, rank 0's
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and line["value"] > 0
+    assert line["gather_check"] == {"bitwise_equal_to_local_recompute": True, "pairs_gathered": 4}
+    assert "parent touched the GPU: False" in r.stderr and "child exit code 0" in r.stderr
+
+
 def _cov_conf_config(mod):
     """Tiny model whose uncertainty head carries all three named outputs of ufm.py:644-660."""
     cfg = mod.ufm_tiny_config()
