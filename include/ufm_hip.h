@@ -140,7 +140,11 @@ int ufm_cross_attention_bf16x3(const uint16_t* q, int ldq, const uint16_t* k, co
  * streams, the way the reference's users run independent pair batches side by side -- flags those streams once: launches on a flagged stream of
  * 8192 rows or more then use full-height 8-phase tiles only (fewer, more efficient workgroups: less CU time taken from the neighbour stream;
  * +1...+2.4 % pairs/s "fast", +2.2...+2.8 % "precise" in the two-stream pipeline, -0.8 % if the stream in fact runs alone).  Results are bitwise
- * the same either way.  on = 0 removes the flag.  At most 32 streams; the null stream cannot be flagged.  Thread-safe. */
+ * the same either way.  Flags are REFERENCE-COUNTED per handle (round 6): every successful on = 1 is paired with one on = 0 by its
+ * holder (the engine un-flags its streams when it is destroyed), the flag goes with the last reference; on = 0 for an unknown handle is a
+ * no-op.  At most 32 distinct streams (UFM_ERR_ARG beyond: the caller should say so, the launch policy silently stays "latency" on that
+ * stream); the null stream cannot be flagged.  A stale flag -- a holder that never gives it back, or a destroyed stream whose handle the
+ * runtime hands out again -- changes the tile policy of launches on that handle only, never a result bit.  Thread-safe. */
 int ufm_hint_concurrent_stream(void* stream, int on);
 /* Tuning hooks (tests / tools only; the product path never calls them).
  * variant: 0 = auto (cost model per shape), 1 = 128x128 kernel, 4 = 256x256 8-phase kernel, 5 = hybrid (8-phase on the rows
@@ -159,6 +163,10 @@ int ufm_hint_concurrent_stream(void* stream, int on);
 int ufm_debug_set_gemm_variant(int variant);
 int ufm_debug_set_gemm_flags(int flags);
 int ufm_debug_set_gemm_tile_rows(int rows);
+/* The lab flag words' field tables (ufm_amd/csrc/lab_flags.h: ONE table of {name, shift, width} per word, pairwise disjoint at compile
+ * time; every consumer reads its field masked to its width; the two setters return UFM_ERR_ARG for any bit outside the table).
+ * word 0 = ufm_debug_set_gemm_flags, word 1 = ufm_debug_set_conv_variant; index 0.. until UFM_ERR_ARG.  Host only, no GPU call. */
+int ufm_debug_lab_field(int word, int index, const char** name, int* shift, int* width);
 /* In-kernel stamps of the 8-phase and pair GEMM kernels (diagnostic instantiations; the shipped kernels execute no stamp):
  * while `buf` is set, launches with the fc1 (bias + GELU -> bf16) or proj / fc2 (bias + LayerScale + fp32 residual) epilogue
  * write 8 x uint64 per workgroup b < rows: {b | HW_ID << 32, XCC_ID | LDS_ALLOC << 32, s_memtime at entry, after the K loop,

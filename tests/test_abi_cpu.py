@@ -161,3 +161,78 @@ def test_split_precision_attention_isa_audit_runs_in_the_build_and_catches_a_com
         bad.write_text(t)
         r = subprocess.run([sys.executable, tool, str(bad)], capture_output=True, text=True)
         assert r.returncode != 0, (i, r.stdout[-400:])
+
+
+def _lab_table(lib, word):
+    fields, i = [], 0
+    while True:
+        name, shift, width = ctypes.c_char_p(), ctypes.c_int32(), ctypes.c_int32()
+        rc = lib.ufm_debug_lab_field(word, i, ctypes.byref(name), ctypes.byref(shift), ctypes.byref(width))
+        if rc != 0:
+            return fields
+        fields.append((name.value.decode(), shift.value, width.value))
+        i += 1
+
+
+def test_lab_flag_words_have_one_disjoint_table_and_refuse_unknown_bits(lib):
+    """VERDICT r5 item 7a.  `gemm_bf16_8ph.hip` once decoded a field as `flags >> 8` without a mask, so every lab bit added above it
+    silently changed the kernel's tile order in one arm of four A/Bs.  Now: one {name, shift, width} table per word
+    (ufm_amd/csrc/lab_flags.h, static_assert'ed disjoint), every consumer reads through lab_get() (masked to the field's width), and
+    the setters return UFM_ERR_ARG for any bit outside the table instead of dropping or mis-reading it."""
+    for word, setter in ((0, lib.ufm_debug_set_gemm_flags), (1, lib.ufm_debug_set_conv_variant)):
+        fields = _lab_table(lib, word)
+        assert len(fields) >= 6 and len({f[0] for f in fields}) == len(fields)
+        seen = 0
+        for name, shift, width in fields:
+            m = ((1 << width) - 1) << shift
+            assert width >= 1 and shift >= 0 and shift + width <= 31, name
+            assert seen & m == 0, f"field {name} overlaps another field of word {word}"
+            seen |= m
+        try:
+            for bit in range(31):
+                rc = setter(1 << bit)
+                if seen >> bit & 1:
+                    # a bit of a known field: accepted unless the field's own value check refuses it (conv kernel ids > 4, tile heights outside 5..8)
+                    assert rc in (0, -1), (word, bit)
+                else:
+                    assert rc == -1 and b"no field of the lab flag table" in lib.ufm_last_error(), (word, bit)
+            assert setter(0) == 0
+        finally:
+            setter(0)
+    assert lib.ufm_debug_lab_field(2, 0, ctypes.byref(ctypes.c_char_p()), ctypes.byref(ctypes.c_int32()), ctypes.byref(ctypes.c_int32())) == -1
+    assert lib.ufm_debug_set_conv_variant(5) == -1 and lib.ufm_debug_set_conv_variant(2 | (4 << 8)) == -1 and lib.ufm_debug_set_conv_variant(2 | (6 << 8)) == 0
+    lib.ufm_debug_set_conv_variant(0)
+    assert lib.ufm_debug_set_upsample_variant(4) == -1 and lib.ufm_debug_set_upsample_variant(1) == 0
+    assert lib.ufm_debug_set_attn_variant(8) == -1 and lib.ufm_debug_set_attn_variant(0) == 0
+    # no consumer decodes a lab word by hand: every read of GemmArgs::debug / the two globals goes through lab_get / lab_mask
+    csrc = os.path.join(REPO, "ufm_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".h", ".cpp")) or f == "lab_flags.h":
+            continue
+        for n, ln in enumerate(open(os.path.join(csrc, f)), 1):
+            code = ln.split("//")[0]
+            for word in ("p.debug", "q.debug", "g_gemm_flags", "g_conv_variant_all"):
+                for m in re.finditer(re.escape(word) + r"\s*(>>|&(?!&))", code):
+                    tail = code[m.end():]
+                    assert re.match(r"\s*\(?\s*~?lab_(mask|known)\(", tail), f"{f}:{n}: raw decode of {word}: {ln.strip()[:120]}"
+
+
+def test_persistent_gemm_audit_counts_the_stores_behind_the_next_tiles_prologue(tmp_path):
+    """gemm_bf16_8ph_persist_kernel's follow-on tiles wait vmcnt(8 + 16): exactly 16 row stores (and nothing else that counts
+    in vmcnt) must sit between a wave's prologue LDS-DMAs of the next tile and that tile's counted waits.  The build audits it
+    (tools/check_attn_x3_isa.py, run by the Makefile); here the audit passes on the built assembly and fails on a copy with one store split."""
+    import sys
+
+    csrc = os.path.join(REPO, "ufm_amd", "csrc")
+    subprocess.run(["make", "-C", csrc, "build/gemm_bf16_8ph_persist.o"], check=True, capture_output=True)
+    asm = os.path.join(csrc, "build", "gemm_bf16_8ph_persist-hip-amdgcn-amd-amdhsa-gfx950.s")
+    tool = os.path.join(REPO, "tools", "check_attn_x3_isa.py")
+    ok = subprocess.run([sys.executable, tool, asm, "gemm_bf16_8ph_persist_kernel"], capture_output=True, text=True)
+    assert ok.returncode == 0 and "exactly 16 row stores" in ok.stdout, ok.stdout
+    txt = open(asm).read()
+    m = re.search(r"global_store_dwordx4 (v\[\d+:\d+\]), v\[(\d+):(\d+)\], off", txt)
+    split_store = f"global_store_dwordx2 {m.group(1)}, v[{m.group(2)}:{int(m.group(2)) + 1}], off\n\tglobal_store_dwordx2 {m.group(1)}, v[{int(m.group(2)) + 2}:{m.group(3)}], off offset:8"
+    bad = tmp_path / "bad_persist.s"
+    bad.write_text(txt.replace(m.group(0), split_store, 1))
+    r = subprocess.run([sys.executable, tool, str(bad), "gemm_bf16_8ph_persist_kernel"], capture_output=True, text=True)
+    assert r.returncode != 0 and "15 global_store_dwordx4" in r.stdout and "other than the 16 row stores" in r.stdout, r.stdout[-600:]

@@ -1102,6 +1102,42 @@ def test_gemm_bf16x3(hip, M, N, K, act, use_gamma, use_res, split_out):
         assert torch.equal(out2.view(torch.int16), out.view(torch.int16))
 
 
+@pytest.mark.parametrize("M,N,K,use_res,act", [(512, 256, 128, True, 0), (512, 256, 128, False, 0), (512, 256, 128, False, 2)])
+def test_gemm_bf16x3_nan_in_is_nan_out_in_the_grouped_epilogue(hip, M, N, K, use_res, act):
+    """the grouped (round 5) epilogue applied 'no activation' as fmaxf(v, -inf) -- fmaxf returns its non-NaN operand, so a NaN
+    accumulator became -inf (fp32 residual stream) or (hi = -inf, lo = NaN) in the split store, where the serial per-pass read-out
+    (variant + 16) kept the NaN.  Now ReLU / identity are one signed-integer max on the bit pattern in BOTH forms: a NaN row stays NaN,
+    and the two forms agree bit for bit on NaN data too (act 0: fp32 read-modify-write and split store; act 2 = ReLU: NaN stays NaN)."""
+    lib = hip.lib()
+    A = rnd(M, K, seed=1)
+    A[7, 3] = float("nan")      # row 7 of the output is NaN in every column
+    A[300, 100] = float("inf")  # row 300: +-inf products of both signs -> NaN / inf mix
+    W = rnd(N, K, seed=2, scale=K**-0.5)
+    As, Ws = split(A).to(DEV), split(W).to(DEV)
+    bias, zero = rnd(N, seed=3, scale=0.1).to(DEV), torch.zeros(256, device=DEV)
+    res = rnd(M, N, seed=5).to(DEV)
+    outs = []
+    try:
+        for variant in (0, 16):
+            lib.ufm_debug_set_conv_variant(variant)
+            if use_res:
+                o = res.clone()
+                hip.gemm_x3(As, Ws, M, N, K, o, zero, bias=bias, res=o)
+                outs.append(o.view(torch.int32).clone())
+            else:
+                o = torch.full((2, M, N), 7.0, device=DEV, dtype=torch.bfloat16)
+                hip.gemm_x3(As, Ws, M, N, K, o, zero, bias=bias, act=act)
+                outs.append(o.view(torch.int16).clone())
+    finally:
+        lib.ufm_debug_set_conv_variant(0)
+    assert torch.equal(outs[0], outs[1])
+    val = outs[0].view(torch.float32) if use_res else unsplit(outs[0].view(torch.bfloat16))
+    assert torch.isnan(val[7]).all() and torch.isnan(val[300]).any()
+    keep = torch.ones(M, dtype=torch.bool)
+    keep[7] = keep[300] = False
+    assert torch.isfinite(val[keep.to(val.device)]).all()
+
+
 def test_split_format_gelu_epilogue_against_fp64_gelu(hip):
     """The GELU of every split-format epilogue (conv_x3_common.h: gelu_erf_fast -- Abramowitz-Stegun 7.1.26 on v_rcp_f32 /
     v_exp2_f32) measured directly: a 32 x 32 identity weight and every bf16 value of [-8, 8] as the operand, so the

@@ -74,6 +74,18 @@ expect((-1,), lib.ufm_hint_concurrent_stream(C.c_void_p(0x999000), 1), "table fu
 for h in range(1, 33):
     expect((0,), lib.ufm_hint_concurrent_stream(C.c_void_p(0x1000 * h), 0), "remove the flag")
 expect((0,), lib.ufm_hint_concurrent_stream(C.c_void_p(0x999000), 0), "removing an unknown stream is not an error")
+# round 6: flags are reference-counted per handle -- 0x1000 was taken twice and given back once, so it still owns a slot
+for h in range(2, 33):
+    expect((0,), lib.ufm_hint_concurrent_stream(C.c_void_p(0x1000 * h), 1), "31 other streams fit")
+expect((-1,), lib.ufm_hint_concurrent_stream(C.c_void_p(0x999000), 1), "the twice-flagged handle still holds its slot")
+expect((0,), lib.ufm_hint_concurrent_stream(C.c_void_p(0x1000), 0), "second holder gives it back")
+expect((0,), lib.ufm_hint_concurrent_stream(C.c_void_p(0x999000), 1), "now the slot is free")
+for h in list(range(2, 33)) + [0x999]:
+    expect((0,), lib.ufm_hint_concurrent_stream(C.c_void_p(0x1000 * h), 0), "clean up")
+# the lab flag words refuse bits outside their field tables (csrc/lab_flags.h)
+expect((-1,), lib.ufm_debug_set_gemm_flags(1), "bit 0 belongs to no field")
+expect((-1,), lib.ufm_debug_set_conv_variant(1 << 21), "bit 21 belongs to no field")
+expect((0,), lib.ufm_debug_set_conv_variant(0), "conv variant off")
 expect((-1,), lib.ufm_gather_rows_f32(P, 62, P, 4, 64, P, 64, None), "gather ld")
 expect((-1,), lib.ufm_debug_set_gemm_variant(3), "variant")
 expect((-1,), lib.ufm_debug_set_gemm_tile_rows(100), "tile rows")

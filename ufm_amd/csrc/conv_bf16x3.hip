@@ -259,6 +259,12 @@ static int g_conv_variant_all = 0;
 // 3 = 128-row kernels only and never the deep (NS = 4) ring; + 16 = the serial (per-pass) residual read-out of rounds 1-4;
 // bits 8..11 = pinned 8-phase tile height; bits 12..18 (with stamps set) = timing ablations of the 8-phase loop (ConvX3Args::ablate); bits 19 / 20 = the latency / the CU-time objective of the tile-height choice on every stream (default: by ufm_hint_concurrent_stream)
 extern "C" int ufm_debug_set_conv_variant(int v) {
+    // fields: lab_flags.h conv_lab::ALL (one table; disjoint at compile time); a bit outside the table is refused
+    const unsigned unknown = (unsigned)v & ~lab_known(conv_lab::ALL);
+    UFM_REQUIRE(unknown == 0, "ufm_debug_set_conv_variant: bits 0x%x belong to no field of the lab flag table (lab_flags.h)", unknown);
+    UFM_REQUIRE(lab_get(v, conv_lab::KERNEL) <= 4, "ufm_debug_set_conv_variant: kernel %d is not in 0..4", lab_get(v, conv_lab::KERNEL));
+    const int nfp = lab_get(v, conv_lab::NF_PIN);
+    UFM_REQUIRE(nfp == 0 || (nfp >= 5 && nfp <= 8), "ufm_debug_set_conv_variant: pinned tile height nf = %d is not 0 or 5..8", nfp);
     g_conv_variant_all = v;
     return UFM_OK;
 }
@@ -290,11 +296,11 @@ extern "C" long long ufm_conv_x3_splitk_ws_bytes(int groups, int B, int H, int W
 // Kernel choice for one problem (shared by the convolution and the Linear entry points).
 static void launch_conv_x3(const ConvX3Args& p_in, int passes, hipStream_t stream) {
     ConvX3Args p = p_in;
-    p.serial_epilogue = (g_conv_variant_all >> 4) & 1;
+    p.serial_epilogue = lab_get(g_conv_variant_all, conv_lab::SERIAL_EPILOGUE);
     p.stamps = g_conv_stamps, p.stamp_rows = g_conv_stamp_rows;
-    p.ablate = g_conv_stamps ? (g_conv_variant_all >> 12) & 127 : 0;  // (only the stamped instantiation reads it)
-    const int nf_pin = (g_conv_variant_all >> 8) & 15;  // tools / tests: pin the 8-phase tile height (5..8 fragments per wave row)
-    const int g_conv_variant = g_conv_variant_all & 15;
+    p.ablate = g_conv_stamps ? lab_get(g_conv_variant_all, conv_lab::ABLATE) : 0;  // (only the stamped instantiation reads it)
+    const int nf_pin = lab_get(g_conv_variant_all, conv_lab::NF_PIN);  // tools / tests: pin the 8-phase tile height (5..8 fragments per wave row)
+    const int g_conv_variant = lab_get(g_conv_variant_all, conv_lab::KERNEL);
     const int Cout = p.Cout, KH = p.KH, KW = p.KW, Cin = p.Cin;
     const long long M = p.M;
     const int S = p.splitk;
@@ -367,7 +373,7 @@ static void launch_conv_x3(const ConvX3Args& p_in, int passes, hipStream_t strea
         // what counts is the CU time a launch takes from the other stream's kernels: lower tiles and the 128-row rest launch finish a lone launch
         // sooner and cost more CU time.  There, from 8192 rows on: full-height tiles, no hybrid split -- numerics "precise" +2.2...+2.8 % pairs/s,
         // "fast" +-0 (profiles/r05/gemm_tile_policy_pipeline.log).  Variant bits 19 / 20 (lab): the latency / the CU-time objective on every stream.
-        const bool throughput = ((g_conv_variant_all >> 20) & 1) || (ufm_stream_is_concurrent(stream) && !((g_conv_variant_all >> 19) & 1));
+        const bool throughput = lab_get(g_conv_variant_all, conv_lab::CU_TIME) || (ufm_stream_is_concurrent(stream) && !lab_get(g_conv_variant_all, conv_lab::LATENCY));
         const bool only8 = M >= 8192 && throughput;
         constexpr double FIX = 0.65;
         double best = 1e30;

@@ -1,6 +1,7 @@
 // Shared pieces of the bf16x3 convolution kernels (conv_bf16x3.hip, conv_bf16x3_8ph.hip).
 #pragma once
 #include "common.h"
+#include "lab_flags.h"
 
 struct ConvX3Args {
     const uint16_t* in;   // [2][B*H*W][Cin]
@@ -80,6 +81,9 @@ static __device__ __forceinline__ f32x4 split_load4(const uint16_t* hi_ptr, long
 // 128/64 B per plane, contiguous).  Chunk index XOR row keeps both the accumulator-shaped writes and the row-shaped
 // reads conflict-free.  LDS ops of one wave execute in order: no barrier between the writes and the reads.
 // TMU <= TM: only the first TMU 16-row fragments of the accumulator array exist (8-phase tiles lower than 256 rows).
+// ReLU on the bit pattern (negative floats are negative integers): NaN stays NaN (fmaxf(NaN, 0) = 0), -0.0 -> +0.0
+static __device__ __forceinline__ float relu_bits(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
+
 template <int TM, int TN, int TMU = TM>
 static __device__ __forceinline__ void conv_x3_epilogue(const ConvX3Args& p, f32x4 (&acc)[TN][TM], char* ws, int pix0, int cb0, int lane, int g = 0) {
     static_assert(TMU >= 1 && TMU <= TM, "TMU");
@@ -118,7 +122,10 @@ static __device__ __forceinline__ void conv_x3_epilogue(const ConvX3Args& p, f32
                      : (p.out_f32 ? (p.res_f32 ? 3 : 0) : (p.res1 ? (p.res2 ? 2 : 1) : 4));
     if (mode != 0 && !p.serial_epilogue) {
         const int cb = cb0 + oc * 4;
-        const float lo = (p.act == UFM_ACT_RELU) ? 0.0f : -__builtin_inff();  // fmaxf(v, -inf) == v
+        // ReLU / no activation as ONE signed-integer max on the bit pattern (negative floats are negative integers): floor 0 = ReLU, floor
+        // INT_MIN = identity.  Round 6: the float form fmaxf(v, -inf) turned a NaN accumulator into -inf (fmaxf returns its
+        // non-NaN operand) where the serial path kept it; the integer form is the identity on every bit pattern, NaN included.
+        const int lo = (p.act == UFM_ACT_RELU) ? 0 : (int)0x80000000;
         f32x4 gv = {1.f, 1.f, 1.f, 1.f};
         __builtin_amdgcn_s_waitcnt(0x0F70);  // compiler-visible vmcnt(0): clears the K loop's LDS-DMA from hipcc's scoreboard (all landed)
         if (p.gamma) gv = *(const f32x4*)(p.gamma + cb);
@@ -150,7 +157,7 @@ static __device__ __forceinline__ void conv_x3_epilogue(const ConvX3Args& p, f32
                         for (int j = 0; j < 4; ++j) v[j] = gelu_erf_fast(v[j]);
                     } else {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], lo);
+                        for (int j = 0; j < 4; ++j) v[j] = __int_as_float(max(__float_as_int(v[j]), lo));
                     }
                     v *= gv;
                     auto unsplit = [](const u32x2& ph, const u32x2& pl) {
@@ -170,7 +177,7 @@ static __device__ __forceinline__ void conv_x3_epilogue(const ConvX3Args& p, f32
                         split_store4(p.out + o, p.out_plane, v);
                         if (p.out_relu) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+                            for (int j = 0; j < 4; ++j) v[j] = relu_bits(v[j]);
                             split_store4(p.out_relu + o, p.out_plane, v);
                         }
                     }
@@ -207,9 +214,9 @@ static __device__ __forceinline__ void conv_x3_epilogue(const ConvX3Args& p, f32
             // stored in); libm's branchy erff made the GELU epilogue of the precise-mode fc1 GEMM 15 % of its launch
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = gelu_erf_fast(v[j]);
-        } else if (p.act != UFM_ACT_NONE) {
+        } else if (p.act == UFM_ACT_RELU) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act);
+            for (int j = 0; j < 4; ++j) v[j] = relu_bits(v[j]);
         }
         const size_t o = (size_t)pix * p.Cout + cb;
         if (p.gamma) v *= *(const f32x4*)(p.gamma + cb);
@@ -223,7 +230,7 @@ static __device__ __forceinline__ void conv_x3_epilogue(const ConvX3Args& p, f32
         split_store4(p.out + o, p.out_plane, v);
         if (p.out_relu) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+            for (int j = 0; j < 4; ++j) v[j] = relu_bits(v[j]);
             split_store4(p.out_relu + o, p.out_plane, v);
         }
     }

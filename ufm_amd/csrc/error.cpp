@@ -5,8 +5,10 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <mutex>
 
 #include "../../include/ufm_hip.h"
+#include "lab_flags.h"
 
 static thread_local char g_err[512] = "";
 
@@ -38,26 +40,40 @@ int ufm_device_cu_count() {
 
 // Streams the caller has declared to run CONCURRENTLY with others of its own (ufm_hint_concurrent_stream): the tile-height choice of the
 // GEMM / bf16x3 dispatch then minimises the CU time a launch takes from its neighbours instead of its own latency.  A small fixed table,
-// written rarely (an engine flags its micro-batch streams when it creates them), read on every GEMM / convolution launch.
-static std::atomic<void*> g_conc_streams[32];
+// written rarely (an engine flags its micro-batch streams when it creates them and un-flags them when it dies), read lock-free on every
+// GEMM / convolution launch.  Entries are REFERENCE-COUNTED per handle (round 6): stream handles come out of a small pool and two engines
+// may hold the same one -- the flag goes when the last holder gives it back, and a handle given back more often than taken is an error.
+// A stale flag (a holder that never un-flags; a destroyed stream whose address is reused) costs tile policy only, never bits.
+static constexpr int CONC_SLOTS = 32;
+static std::atomic<void*> g_conc_streams[CONC_SLOTS];
+static int g_conc_refs[CONC_SLOTS];  // guarded by g_conc_mutex
+static std::mutex g_conc_mutex;
 extern "C" int ufm_hint_concurrent_stream(void* stream, int on) {
     if (stream == nullptr) {
         ufm_set_error("ufm_hint_concurrent_stream: the null (legacy default) stream cannot be flagged");
         return UFM_ERR_ARG;
     }
-    for (auto& e : g_conc_streams) {  // already there?
-        void* cur = e.load(std::memory_order_acquire);
-        if (cur == stream) {
-            if (!on) e.store(nullptr, std::memory_order_release);
+    std::lock_guard<std::mutex> lock(g_conc_mutex);
+    for (int i = 0; i < CONC_SLOTS; ++i) {  // already there?
+        if (g_conc_streams[i].load(std::memory_order_acquire) == stream) {
+            if (on) {
+                ++g_conc_refs[i];
+            } else if (--g_conc_refs[i] <= 0) {
+                g_conc_refs[i] = 0;
+                g_conc_streams[i].store(nullptr, std::memory_order_release);
+            }
             return UFM_OK;
         }
     }
-    if (!on) return UFM_OK;
-    for (auto& e : g_conc_streams) {
-        void* expect = nullptr;
-        if (e.compare_exchange_strong(expect, stream, std::memory_order_acq_rel)) return UFM_OK;
+    if (!on) return UFM_OK;  // un-flagging an unknown handle: a no-op (the hint may have been refused when it was asked for)
+    for (int i = 0; i < CONC_SLOTS; ++i) {
+        if (g_conc_streams[i].load(std::memory_order_relaxed) == nullptr) {
+            g_conc_refs[i] = 1;
+            g_conc_streams[i].store(stream, std::memory_order_release);
+            return UFM_OK;
+        }
     }
-    ufm_set_error("ufm_hint_concurrent_stream: more than %d streams flagged", (int)(sizeof(g_conc_streams) / sizeof(g_conc_streams[0])));
+    ufm_set_error("ufm_hint_concurrent_stream: more than %d streams flagged", CONC_SLOTS);
     return UFM_ERR_ARG;
 }
 bool ufm_stream_is_concurrent(void* stream) {
@@ -65,4 +81,16 @@ bool ufm_stream_is_concurrent(void* stream) {
     for (auto& e : g_conc_streams)
         if (e.load(std::memory_order_relaxed) == stream) return true;
     return false;
+}
+
+// The lab flag tables (lab_flags.h), walkable from outside: word 0 = ufm_debug_set_gemm_flags, 1 = ufm_debug_set_conv_variant.
+extern "C" int ufm_debug_lab_field(int word, int index, const char** name, int* shift, int* width) {
+    const LabField* t = word == 0 ? gemm_lab::ALL : word == 1 ? conv_lab::ALL : nullptr;
+    const int n = word == 0 ? (int)(sizeof(gemm_lab::ALL) / sizeof(LabField)) : word == 1 ? (int)(sizeof(conv_lab::ALL) / sizeof(LabField)) : 0;
+    if (t == nullptr || index < 0 || index >= n || !name || !shift || !width) {
+        ufm_set_error("ufm_debug_lab_field: word %d has no field %d", word, index);
+        return UFM_ERR_ARG;
+    }
+    *name = t[index].name, *shift = t[index].shift, *width = t[index].width;
+    return UFM_OK;
 }

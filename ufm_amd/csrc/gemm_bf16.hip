@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, KS == 1 ? 2 : 1) void gemm_bf16_kernel(GemmArg
         gw[i] = p.W + (size_t)(n0 + r) * p.ldw + chunk * 8;
     }
     auto stage = [&](int buf, int kt) {
-        if (p.debug & 2) return;  // ablation (tools/): no DMA
+        if (lab_get(p.debug, gemm_lab::NO_DMA)) return;  // ablation (tools/): no DMA
         char* sa = smem + buf * STAGE_BYTES + wave * 4096;
         char* sb = sa + BM * BK * 2;
 #pragma unroll
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256, KS == 1 ? 2 : 1) void gemm_bf16_kernel(GemmArg
         }
     }
 
-    if (p.debug & 4) {  // ablation (tools/): no epilogue traffic; keep the accumulators live
+    if (lab_get(p.debug, gemm_lab::NO_EPILOGUE)) {  // ablation (tools/): no epilogue traffic; keep the accumulators live
         float keep = 0.f;
 #pragma unroll
         for (int n = 0; n < 4; ++n)
@@ -138,14 +138,14 @@ __global__ __launch_bounds__(256, KS == 1 ? 2 : 1) void gemm_bf16_kernel(GemmArg
         if (keep == 123.456f) ((float*)p.out)[0] = keep;
         return;
     }
-    if (p.debug & 8) {  // A/B hook: the direct (unstaged) epilogue
+    if (lab_get(p.debug, gemm_lab::DIRECT_EPILOGUE)) {  // A/B hook: the direct (unstaged) epilogue
         epilogue<OUT_BF16>(p, acc, m0 + wr * 64, n0 + wc * 64, fr, fq);
         return;
     }
     __syncthreads();  // every wave is done reading the staging buffers
     if constexpr (!OUT_BF16) {
         // the transformer's read-modify-write form on a whole slice: residual loads out of the store chain (gemm_common.h, round 5)
-        if (p.res && p.bias && p.act == UFM_ACT_NONE && p.res_row_mod == 0 && p.out_row_group == 0 && m0 + wr * 64 + 64 <= p.M && !(p.debug & 0x800000)) {
+        if (p.res && p.bias && p.act == UFM_ACT_NONE && p.res_row_mod == 0 && p.out_row_group == 0 && m0 + wr * 64 + 64 <= p.M && !lab_get(p.debug, gemm_lab::SERIAL_RMW)) {
             epilogue_lds_rmw2<0, 5>(p, acc, acc, smem + wave * 16384, m0 + wr * 64, n0 + wc * 64, lane);
             return;
         }
@@ -185,7 +185,10 @@ extern "C" int ufm_debug_set_gemm_stamps(unsigned long long* buf, int rows) {
     return UFM_OK;
 }
 extern "C" int ufm_debug_set_gemm_flags(int flags) {
-    g_gemm_flags = flags & (2 | 4 | 8 | 16 | 32 | 64 | 128 | 0xff00 | 0x7f0000 | 0x800000 | 0xf000000 | 0x10000000 | 0x20000000 | 0x40000000);  // 0x20000000 / 0x40000000 (lab): the latency / the CU-time objective of the tile-height choice on every stream (default: by ufm_hint_concurrent_stream)  // 0x10000000: never the persistent 8-phase kernel (A/B)  // 0xf000000: flip the four auto rules of the pair kernel (A/B)  // 0x800000: the serial read-modify-write read-out (A/B of round 5's pipelined one)  // 0x70000: start stagger of the 8-phase kernel's first round (lab)  // 128: never the two-K-tiles-per-barrier form of the 128x128 kernel  // 64: generic (run-time switched) epilogue in the 8-phase kernels  // 16 / 32: lda / ldw = 0 (every tile reads the same rows: an all-L2-hit probe, tools/lab)
+    // fields: lab_flags.h gemm_lab::ALL (one table; disjoint at compile time); a bit outside the table is refused, not dropped
+    const unsigned unknown = (unsigned)flags & ~lab_known(gemm_lab::ALL);
+    UFM_REQUIRE(unknown == 0, "ufm_debug_set_gemm_flags: bits 0x%x belong to no field of the lab flag table (lab_flags.h)", unknown);
+    g_gemm_flags = flags;
     return UFM_OK;
 }
 
@@ -219,8 +222,8 @@ extern "C" int ufm_gemm_bf16_rope(const uint16_t* A, int lda, const uint16_t* W,
     UFM_REQUIRE(out_dtype == UFM_F32 || out_dtype == UFM_BF16, "ufm_gemm_bf16: bad out_dtype %d", out_dtype);
     UFM_REQUIRE((size_t)M * (size_t)(lda > ldo ? lda : ldo) < (1ull << 40), "ufm_gemm_bf16: problem too large");
     GemmArgs p{A, W, bias, gamma, res, out, lda, ldw, M, N, K, act, ldres, res_row_mod, ldo, out_row_group, g_gemm_flags, 0, rope_cos, rope_sin, rope_mod, rope_cols, g_gemm_stamps, g_gemm_stamp_rows};
-    if (g_gemm_flags & 16) p.lda = 0;
-    if (g_gemm_flags & 32) p.ldw = 0;
+    if (lab_get(g_gemm_flags, gemm_lab::LDA0)) p.lda = 0;
+    if (lab_get(g_gemm_flags, gemm_lab::LDW0)) p.ldw = 0;
     const int NCU = ufm_device_cu_count();  // whole rounds of the one-block-per-CU 8-phase kernel
     const int ntn = N / 256;
     // variant: 0 auto, 1 = 128x128, 4 = 8-phase on all rows, 5 = hybrid (256-row 8-phase tiles on the leading rows that fill
@@ -254,7 +257,7 @@ extern "C" int ufm_gemm_bf16_rope(const uint16_t* A, int lda, const uint16_t* W,
         // a lone proj 7 % sooner than 172 tiles of 256 rows, but occupy 25 % more CU time that the other stream's kernels could have used.  There,
         // from 8192 rows on, only full-height tiles are considered: +1.0...+2.4 % pairs/s in the pipeline, -0.8 % on a single stream -- hence the
         // hint (profiles/r05/gemm_tile_policy_pipeline.log).  Flag bits 29 / 30 (lab): the latency / the CU-time objective on every stream.
-        const bool throughput = ((g_gemm_flags >> 30) & 1) || (ufm_stream_is_concurrent(stream) && !((g_gemm_flags >> 29) & 1));
+        const bool throughput = lab_get(g_gemm_flags, gemm_lab::CU_TIME) || (ufm_stream_is_concurrent(stream) && !lab_get(g_gemm_flags, gemm_lab::LATENCY));
         const bool only8 = rows >= 8192 && throughput;
         for (int nf = 8; nf >= 5; --nf) {
             if (g_gemm_tile_rows && 32 * nf != g_gemm_tile_rows) continue;
@@ -295,7 +298,7 @@ extern "C" int ufm_gemm_bf16_rope(const uint16_t* A, int lda, const uint16_t* W,
     int nf_pair = g_gemm_tile_rows ? g_gemm_tile_rows / 32 : 8;
     if (g_gemm_variant == 0 && K >= 128 && fits32 && !g_gemm_tile_rows) {
         constexpr int PAIR_DEFAULT = 7;
-        const int pol = PAIR_DEFAULT ^ ((g_gemm_flags >> 24) & 15);
+        const int pol = PAIR_DEFAULT ^ lab_get(g_gemm_flags, gemm_lab::PAIR_FLIP);
         const bool small = M < 16000;
         int nfp = 0;
         if (out_dtype == UFM_BF16) {
@@ -312,7 +315,7 @@ extern "C" int ufm_gemm_bf16_rope(const uint16_t* A, int lda, const uint16_t* W,
         const int ntm = (q.M - q.m_begin + BM - 1) / BM, ntn128 = N / BN;
         dim3 grid(ntm * ntn128), block(256);
         // at most one block per CU anyway: two K-tiles per barrier (bit-identical; g_gemm_flags & 128 = never, for A/B)
-        const bool lone = (int)grid.x <= NCU && K >= 4 * BK && !(g_gemm_flags & 128);
+        const bool lone = (int)grid.x <= NCU && K >= 4 * BK && !lab_get(g_gemm_flags, gemm_lab::NO_TWO_KTILES);
         if (out_dtype == UFM_BF16) {
             if (lone) hipLaunchKernelGGL((gemm_bf16_kernel<1, 2>), grid, block, 0, (hipStream_t)stream, q);
             else hipLaunchKernelGGL((gemm_bf16_kernel<1, 1>), grid, block, 0, (hipStream_t)stream, q);
@@ -323,7 +326,7 @@ extern "C" int ufm_gemm_bf16_rope(const uint16_t* A, int lda, const uint16_t* W,
     };
     // the transformer's hot Linear forms get the epilogue specialised at compile time (gemm_common.h EpiTraits); flag 64 = generic
     int epi = 0;
-    const bool plain_rows = res_row_mod == 0 && out_row_group == 0 && !rope_cos && !(g_gemm_flags & 64);
+    const bool plain_rows = res_row_mod == 0 && out_row_group == 0 && !rope_cos && !lab_get(g_gemm_flags, gemm_lab::GENERIC_EPILOGUE);
     if (plain_rows && bias && out_dtype == UFM_BF16 && !res && (ldo & 7) == 0 && ((uintptr_t)out & 15) == 0) {
         if (act == UFM_ACT_GELU && !gamma) epi = 1;
         else if (act == UFM_ACT_NONE && gamma) epi = 2;
@@ -334,12 +337,12 @@ extern "C" int ufm_gemm_bf16_rope(const uint16_t* A, int lda, const uint16_t* W,
     // chip -- the lead part of the hybrid split, or a whole GEMM whose tile count is a multiple of the CU count.  Flag bit 28 = never (A/B).
     auto persist_able = [&](const GemmArgs& q) {  // what the kernel needs: a bf16-output compile-time epilogue, whole 256-row tiles
         const long long rows = q.M - q.m_begin;
-        return (epi == 1 || epi == 2) && out_dtype == UFM_BF16 && ok8 && rows > 0 && rows % 256 == 0 && !q.stamps && !(g_gemm_flags & (2 | 4 | 16 | 32 | 0xff00 | 0x70000));
+        return (epi == 1 || epi == 2) && out_dtype == UFM_BF16 && ok8 && rows > 0 && rows % 256 == 0 && !q.stamps && !(g_gemm_flags & (lab_mask(gemm_lab::NO_DMA) | lab_mask(gemm_lab::NO_EPILOGUE) | lab_mask(gemm_lab::LDA0) | lab_mask(gemm_lab::LDW0) | lab_mask(gemm_lab::RASTER_GROUP) | lab_mask(gemm_lab::STAGGER)));
     };
     auto persist_ok = [&](const GemmArgs& q) {    // where it is dispatched: at least two rounds of the chip, the last one (all but) full
         const long long tiles = ((q.M - q.m_begin) / 256) * ntn;
         const long long short_of = (NCU - tiles % NCU) % NCU;  // the hybrid split's lead part is whole rounds less at most ntn - 1 tiles (whole tile ROWS)
-        return persist_able(q) && tiles + short_of >= 2 * NCU && short_of < ntn && !(g_gemm_flags & (1 << 28));
+        return persist_able(q) && tiles + short_of >= 2 * NCU && short_of < ntn && !lab_get(g_gemm_flags, gemm_lab::NO_PERSIST);
     };
     if (variant == 7) {  // tests / tools: the persistent kernel wherever it can run at all (any tile count), else the 8-phase kernel
         if (persist_able(p)) {

@@ -50,15 +50,15 @@ __device__ __forceinline__ void gemm_bf16_8ph_body(const GemmArgs& p, char* smem
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     // grouped rasterization height (tools/lab/gemm_gm_probe.py: flag bits 8..15); 8 vs 4: QKV -8 %, others +-1 %.  (Until late in round 5 this read ALL bits above 8: every A/B arm
     // that set one of the later lab flags -- bits 16..28 -- also ran this kernel column-major, GM = 2^k; the affected logs say so.)
-    const int GM = ((p.debug >> 8) & 0xff) ? ((p.debug >> 8) & 0xff) : 8;
+    const int GM = lab_get(p.debug, gemm_lab::RASTER_GROUP) ? lab_get(p.debug, gemm_lab::RASTER_GROUP) : 8;
     const int per_group = GM * ntn;
     const int grp = bid / per_group, in_g = bid - grp * per_group;
     const int gm = min(GM, ntm - grp * GM);
     const int m0 = p.m_begin + (grp * GM + in_g % gm) * BMT, n0 = (in_g / gm) << 8;
     const int nt = p.K >> 6;
-    if (p.debug & 0x70000) {  // lab (tools/lab/epi_contention.py): first-round blocks start (block / 8) % 4 x units x ~1 us apart
+    if (lab_get(p.debug, gemm_lab::STAGGER) & 7) {  // lab (tools/lab/epi_contention.py): first-round blocks start (block / 8) % 4 x units x ~1 us apart
         if (blockIdx.x < 256) {
-            const int units = ((p.debug >> 16) & 7) * (int)((blockIdx.x >> 3) & 3);
+            const int units = (lab_get(p.debug, gemm_lab::STAGGER) & 7) * (int)((blockIdx.x >> 3) & 3);
             for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(32);
         }
     }
@@ -203,7 +203,7 @@ __device__ __forceinline__ void gemm_bf16_8ph_body(const GemmArgs& p, char* smem
     if constexpr (STAMP) stamps.t_loop = gemm_stamp();
     // every wave has passed its last ds_read and every DMA has landed (the tail waits end at vmcnt(0)):
     // the staging buffers are free for the epilogue, 16 KiB per wave, two 64x64 passes
-    if (p.debug & 4) {  // ablation (tools/): no epilogue traffic; keep the accumulators live
+    if (lab_get(p.debug, gemm_lab::NO_EPILOGUE)) {  // ablation (tools/): no epilogue traffic; keep the accumulators live
         float keep = 0.f;
 #pragma unroll
         for (int h = 0; h < 2; ++h)

@@ -57,7 +57,7 @@ __device__ __forceinline__ void gemm_bf16_pair_body(const GemmArgs& p, char* sme
 
     // first-round stagger of the second resident workgroup (debug bits 16..22: units of s_sleep(64) ~ 4096 cycles)
     {
-        const int units = (p.debug >> 16) & 0x7f;
+        const int units = lab_get(p.debug, gemm_lab::STAGGER);
         if (units && blockIdx.x < 2 * 256) {
             unsigned lds_alloc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(lds_alloc));
@@ -222,7 +222,7 @@ __device__ __forceinline__ void gemm_bf16_pair_body(const GemmArgs& p, char* sme
     if constexpr (STAMP) stamps.t_loop = gemm_stamp();
     // Every wave retired its last ds_read in front of the last phase's barrier and every DMA has landed (the tail waits end at
     // vmcnt(0)): the rings are free for the epilogue staging, 16 KiB per wave, two 64x64 passes.
-    if (p.debug & 4) {  // ablation (tools/): no epilogue traffic; keep the accumulators live
+    if (lab_get(p.debug, gemm_lab::NO_EPILOGUE)) {  // ablation (tools/): no epilogue traffic; keep the accumulators live
         float keep = 0.f;
 #pragma unroll
         for (int h = 0; h < 2; ++h)

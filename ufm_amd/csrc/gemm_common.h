@@ -1,6 +1,7 @@
 // Shared pieces of the bf16 GEMM kernels (gemm_bf16.hip, gemm_bf16_8ph.hip): argument block, fused epilogues.
 #pragma once
 #include "common.h"
+#include "lab_flags.h"
 
 struct GemmArgs {
     const uint16_t* A;
@@ -11,7 +12,7 @@ struct GemmArgs {
     void* out;
     int lda, ldw, M, N, K;
     int act, ldres, res_row_mod, ldo, out_row_group;
-    int debug;    // diagnostics only (tools/): 1 = every block reads tile (0,0), 2 = no DMA
+    int debug;    // the lab flag word (ufm_debug_set_gemm_flags); fields: lab_flags.h gemm_lab::*, read through lab_get() only
     int m_begin;  // the launch covers rows [m_begin, M) (hybrid 256x256 + 128x128 split of one GEMM); row indices stay absolute
     // fused RoPE-2D (ufm_gemm_bf16_rope, rope.hip): columns [0, rope_cols) of the bf16 output are rotated per 64-wide head with
     // the fp32 tables [rope_mod][64] indexed by row % rope_mod; null tables = no rotation
@@ -265,7 +266,7 @@ __device__ __forceinline__ void epilogue_lds_rmw2(const GemmArgs& p, f32x4 (&acc
 template <int OUT_BF16, int ROWS1, int EPI>
 __device__ __forceinline__ void epilogue_two_slices(const GemmArgs& p, f32x4 (&acc0)[4][4], f32x4 (&acc1)[4][4], char* wave_lds, int row0, int col0, int lane) {
     if constexpr (!OUT_BF16 && (EPI == 3 || EPI == 4)) {
-        if (row0 + 64 + ROWS1 <= p.M && !(p.debug & 0x800000)) {  // debug bit 23: the old serial read-out (A/B)
+        if (row0 + 64 + ROWS1 <= p.M && !lab_get(p.debug, gemm_lab::SERIAL_RMW)) {  // the old serial read-out (A/B)
             epilogue_lds_rmw2<ROWS1, EPI>(p, acc0, acc1, wave_lds, row0, col0, lane);
             return;
         }

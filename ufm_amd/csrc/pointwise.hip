@@ -458,6 +458,7 @@ static int g_upsample_tiled = 1;  // A/B and test hook below: bit 0 clear = one-
 static int g_upsample_flags = 1;  // bit 1: ufm_dpt_tail_fused with the plain (2-way bank-conflicting) T image of rounds 1-4
 int ufm_upsample_variant_flags() { return g_upsample_flags; }
 extern "C" int ufm_debug_set_upsample_variant(int tiled) {
+    UFM_REQUIRE((tiled & ~3) == 0, "ufm_debug_set_upsample_variant: %d has bits outside 0..1", tiled);
     g_upsample_flags = tiled;
     g_upsample_tiled = tiled & 1;
     return UFM_OK;

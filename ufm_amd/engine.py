@@ -27,6 +27,7 @@ Numerics modes
 from __future__ import annotations
 
 import threading
+import warnings
 import weakref
 from typing import Any, Dict, List, Optional, Tuple
 
@@ -65,13 +66,39 @@ class _Lin:
 
 LOG2E = 1.4426950408889634
 
-# Bumped whenever a Parameter is registered on any nn.Module (torch's global hook: also fires for ``module.weight = nn.Parameter(..)``):
-# the engines cache their model's Parameter objects and re-walk the module tree only when this moved.
+# Bumped whenever a Parameter / sub-module / buffer is registered on a module that belongs to a TRACKED model (one an Engine has walked;
+# torch's global registration hooks also fire for ``module.weight = nn.Parameter(..)``): the engines cache their model's Parameter
+# objects and re-walk the module tree only when their model's epoch moved.  Round 6: the epoch used to be process-global, so
+# every nn.Module construction anywhere -- a second model, user code -- made every engine re-walk its tree (0.7-1.7 ms of host time) on
+# its next call; now a registration counts only when the touched module is in a tracked tree (_TRACKED: module -> the epoch cells of the
+# engines whose model contains it).  PARAM_EPOCH stays as the count of ALL registrations (tests, diagnostics).
 PARAM_EPOCH = [0]
+_TRACKED: "weakref.WeakKeyDictionary[nn.Module, Any]" = weakref.WeakKeyDictionary()  # module -> weakref.WeakSet of _Epoch cells
+
+
+class _Epoch:
+    """One engine's 'my model's tree may have changed' counter (weak-referenced from _TRACKED)."""
+
+    __slots__ = ("n", "__weakref__")
+
+    def __init__(self):
+        self.n = 0
 
 
 def _on_parameter_registration(module, name, param):  # noqa: ARG001
     PARAM_EPOCH[0] += 1
+    cells = _TRACKED.get(module)
+    if cells:
+        for c in cells:
+            c.n += 1
+
+
+def _track_tree(model: nn.Module, cell: _Epoch) -> None:
+    for mod in model.modules():
+        s_ = _TRACKED.get(mod)
+        if s_ is None:
+            s_ = _TRACKED[mod] = weakref.WeakSet()
+        s_.add(cell)
 
 
 # The parameter hook alone misses a whole SUB-MODULE swapped in (``model.head1 = other_head``, ``seq[i] = copy.deepcopy(mod)``,
@@ -283,9 +310,46 @@ class _MoGeHead:
         self.shift = [s for a in self.adaptors for s in a.shift]
 
 
-# model -> {numerics: (pack key, {Engine attribute: packed weights})}: one packed copy per (model, numerics), shared by its engines
+# model -> {numerics: weakref to the _Pack}: one packed copy per (model, numerics), shared by its engines.  The ENGINES own the pack
+# (strong reference, Engine._pack_ref); the cache only finds it again.  When the last engine of a numerics mode goes away
+# (set_numerics() drops the eager engine; a GraphedPredictor is deleted) its 0.85-1.7 GB of packed weights are freed (the
+# cache used to hold every mode a model had ever used until the model died).
 _PACK_CACHE: "weakref.WeakKeyDictionary[nn.Module, Dict[str, Any]]" = weakref.WeakKeyDictionary()
-_PER_ENGINE_STATE = frozenset(("_bufs", "_tables", "_packed_key", "_plist", "_plist_epoch", "_tls", "_streams", "_head_streams", "_level_streams", "_head_group"))
+
+
+class _Pack:
+    """Immutable packed weights of one (model, device, numerics, parameter versions): `attrs` = the Engine attributes _pack set."""
+
+    __slots__ = ("key", "attrs", "__weakref__")
+
+    def __init__(self, key, attrs):
+        self.key, self.attrs = key, attrs
+
+
+_PER_ENGINE_STATE = frozenset(("_bufs", "_tables", "_packed_key", "_plist", "_plist_epoch", "_epoch", "_pack_ref", "_tls", "_streams", "_head_streams", "_level_streams", "_head_group",
+                               "_stream_finalizer", "_flagged"))
+
+
+def _unflag_streams(handles: List[int]) -> None:
+    """weakref.finalize target of an Engine: give its micro-batch stream flags back (one reference per flag taken)."""
+    while handles:
+        try:
+            hip.hint_concurrent_stream_handle(handles.pop(), False)
+        except Exception:  # interpreter shutdown: the library may be gone
+            return
+
+
+_HINT_REFUSED = [False]
+
+
+def _warn_hint_refused() -> None:
+    """ufm_hint_concurrent_stream refused (its table of flagged streams is full): results are bitwise the same, but this engine's
+    micro-batch launches keep the latency tile policy (-1...-2.8 % pairs/s in the two-stream pipeline).  Said once, not ignored."""
+    if not _HINT_REFUSED[0]:
+        _HINT_REFUSED[0] = True
+        warnings.warn("ufm_amd: ufm_hint_concurrent_stream refused a micro-batch stream (" + hip.last_error() + "): the GEMM / convolution "
+                      "tile policy falls back to per-launch latency on it; results are unchanged, throughput is 1-3 % lower. "
+                      "Too many live engines with micro-batch streams?", RuntimeWarning, stacklevel=3)
 
 
 class Engine:
@@ -301,6 +365,8 @@ class Engine:
         self._bufs: Dict[str, torch.Tensor] = {}
         self._tables: Dict[Any, Any] = {}
         self._packed_key = None
+        self._pack_ref: Optional[_Pack] = None  # the shared packed weights this engine keeps alive (_PACK_CACHE holds them weakly)
+        self._epoch = _Epoch()  # moves when a Parameter / sub-module / buffer is registered inside THIS model's tree
         self._tls = threading.local()  # .ns = workspace namespace of the micro-batch this thread is running
         # last_layer_view1: the LAST joint-attention block computes its view-1 rows only (queries, proj, MLP on half the rows; keys /
         # values still from both views) -- the reference decodes view 1 only (ufm.py:637-641) and nothing else reads that block's
@@ -314,6 +380,11 @@ class Engine:
         # at 8 images is 485 us against 2 x 270 us at 4 + 4), the two heads on two streams.  Same arithmetic per pair.
         self.joint_heads = True
         self._streams: List[torch.cuda.Stream] = []
+        # raw handles of the micro-batch streams this engine flagged with ufm_hint_concurrent_stream: un-flagged when the engine dies
+        # (the library's table is small and counts references per handle; torch hands stream handles out of a 32-entry pool, so a
+        # flag left behind would re-colour some later engine's head or level stream)
+        self._flagged: List[int] = []
+        self._stream_finalizer = weakref.finalize(self, _unflag_streams, self._flagged)
         # "fast", optional: the residual stream's fp32 read-modify-write is done by the next LayerNorm launch
         # (ufm_add_layernorm) instead of the proj / fc2 GEMM epilogues.  Measured (tools/lab/ab_engine.py, interleaved, same
         # box, B=8 518^2): the GEMM family rises 0.327 -> 0.346 of peak but the step does not move (38.76 vs 38.91 ms with two
@@ -357,9 +428,10 @@ class Engine:
         # Parameter was (re-)registered on ANY module (PARAM_EPOCH: torch's global parameter-registration hook), i.e. when a Parameter
         # object may have been swapped into a sub-module; in-place edits, load_state_dict and .to() show in version / address below.
         plist = getattr(self, "_plist", None)
-        if plist is None or self._plist_epoch != PARAM_EPOCH[0]:
+        if plist is None or self._plist_epoch != self._epoch.n:
+            _track_tree(m, self._epoch)  # (a swapped-in sub-module's own children are tracked from here on)
             plist = self._plist = list(m.parameters())
-            self._plist_epoch = PARAM_EPOCH[0]
+            self._plist_epoch = self._epoch.n
         dev = plist[0].device
         if dev.type != "cuda":
             raise RuntimeError("ufm_amd runs on an AMD GPU only: move the model with .to('cuda') (no CPU fallback exists)")
@@ -374,9 +446,11 @@ class Engine:
         # versions / storage) -- the eager engine and the private engine of each GraphedPredictor -- shares ONE copy (round 5; each
         # used to pack its own 0.85 GB).  Workspace, tables and streams stay per engine.  A graph captured on a shared pack keeps the
         # tensors alive through its engine's references even after the model's weights change and the cache entry is replaced.
-        cached = _PACK_CACHE.setdefault(m, {}).get(self.numerics)
-        if cached is not None and cached[0] == key:
-            self.__dict__.update(cached[1])
+        ref = _PACK_CACHE.setdefault(m, {}).get(self.numerics)
+        cached = ref() if ref is not None else None
+        if cached is not None and cached.key == key:
+            self.__dict__.update(cached.attrs)
+            self._pack_ref = cached
             self._head_group = None
             self._packed_key = key
             return
@@ -461,7 +535,8 @@ class Engine:
                 raise NotImplementedError(f"{what}={d} must be a multiple of 32")
         self._packed_key = key
         packed = {k: v for k, v in self.__dict__.items() if k not in _PER_ENGINE_STATE and k not in self._init_names}  # what _pack set
-        _PACK_CACHE[m][self.numerics] = (key, packed)
+        self._pack_ref = _Pack(key, packed)
+        _PACK_CACHE[m][self.numerics] = weakref.ref(self._pack_ref)
 
     # ------------------------------------------------------------------ small helpers
     def buf(self, name: str, shape: Tuple[int, ...], dtype=torch.float32) -> torch.Tensor:
@@ -1034,7 +1109,11 @@ class Engine:
                 self._view_major_tables(bounds[i + 1] - bounds[i], gh * gw)
         while len(self._streams) < nmb:
             self._streams.append(torch.cuda.Stream(device=self.dev))
-            hip.hint_concurrent_stream(self._streams[-1])  # micro-batch streams run side by side: tile heights for CU time, not latency (include/ufm_hip.h)
+            # micro-batch streams run side by side: tile heights for CU time, not latency (include/ufm_hip.h)
+            if hip.hint_concurrent_stream(self._streams[-1]):
+                self._flagged.append(self._streams[-1].cuda_stream)
+            else:
+                _warn_hint_refused()
         cur = torch.cuda.current_stream(self.dev)
         results: List[Any] = [None] * nmb
         errors: List[BaseException] = []

@@ -59,21 +59,22 @@ class GraphedPredictor:
             model._engine = shared  # eager calls go back to the shared engine (created on demand if there was none)
         # The guard below runs on EVERY replay, in front of the graph launch: walking the module tree (model.parameters()) cost
         # 0.3-0.9 ms of host time per call, 4-9 % of the one-pair latency; reading version + address of a cached list costs 0.08 ms.
-        # A Parameter OBJECT swapped into a sub-module after the capture shows in engine.PARAM_EPOCH (torch's global
-        # parameter-registration hook); in-place edits, load_state_dict and .to() in version / address.  (Edits made through ``p.data``
-        # bump nothing: they are invisible to any guard.)
-        from .engine import PARAM_EPOCH
-
-        self._epoch_ref, self._epoch = PARAM_EPOCH, PARAM_EPOCH[0]
+        # A Parameter OBJECT swapped into a sub-module after the capture shows in the private engine's per-model epoch (torch's global
+        # registration hooks, counted only for modules of THIS model's tree: engine._TRACKED); in-place edits, load_state_dict and .to() in
+        # version / address.  (Edits made through ``p.data`` bump nothing: they are invisible to any guard.)
+        self._epoch_ref, self._epoch = eng._epoch, eng._epoch.n
         self._plist = list(self.model.parameters())
         self._weights_key = self._params_key()
 
     def _params_key(self):
-        if self._epoch_ref[0] != self._epoch:  # a Parameter was registered somewhere (any module, any model): is it one of ours?
+        if self._epoch_ref.n != self._epoch:  # something was registered on a module of this model's tree: did a Parameter object change?
+            from .engine import _track_tree
+
             fresh = list(self.model.parameters())
             if len(fresh) != len(self._plist) or any(a is not b for a, b in zip(fresh, self._plist)):
                 return None  # never equal to the captured key
-            self._epoch = self._epoch_ref[0]
+            _track_tree(self.model, self._epoch_ref)  # (a swapped-in sub-module's own children count from here on)
+            self._epoch = self._epoch_ref.n
         return tuple((p._version, p.data_ptr()) for p in self._plist)
 
     def __call__(self, source_image: torch.Tensor, target_image: torch.Tensor) -> UFMOutputInterface:

@@ -41,6 +41,7 @@ SIGNATURES = {
     "ufm_debug_set_gemm_variant": [_i],
     "ufm_debug_set_gemm_flags": [_i],
     "ufm_debug_set_gemm_tile_rows": [_i],
+    "ufm_debug_lab_field": [_i, _i, C.POINTER(C.c_char_p), _ip, _ip],
     "ufm_debug_set_gemm_stamps": [_vp, _i],
     "ufm_debug_set_conv_stamps": [_vp, _i],
     "ufm_debug_set_attn_variant": [_i],
@@ -206,7 +207,17 @@ def resize_antialias(img: torch.Tensor, layout: int, B: int, H: int, W: int, sca
 def hint_concurrent_stream(stream: "torch.cuda.Stream", on: bool = True) -> bool:
     """Tell the library that ``stream`` runs side by side with other streams of the caller (ufm_hint_concurrent_stream): launches on it then
     choose tile heights for CU time, not for their own latency.  A hint: returns False instead of raising when the table is full."""
-    return lib().ufm_hint_concurrent_stream(C.c_void_p(stream.cuda_stream), 1 if on else 0) == 0
+    return hint_concurrent_stream_handle(stream.cuda_stream, on)
+
+
+def hint_concurrent_stream_handle(handle: int, on: bool = True) -> bool:
+    """The same by raw hipStream_t value (an Engine's finalizer un-flags its streams after the torch objects are gone).  The library counts
+    references per handle: every successful on=True must be paired with one on=False."""
+    return lib().ufm_hint_concurrent_stream(C.c_void_p(handle), 1 if on else 0) == 0
+
+
+def last_error() -> str:
+    return lib().ufm_last_error().decode(errors="replace")
 
 
 def gemm_bf16(A, W, M, N, K, out, *, bias=None, act=ACT_NONE, gamma=None, res=None, ldres=0, res_row_mod=0, lda=None, ldw=None, ldo=None, out_row_group=0, rope=None):
