@@ -27,6 +27,7 @@ Rank 0 prints ONE JSON line.  Extra objects:
                 HIP-graph replay (ufm_amd.GraphedPredictor).
   config4 / config5   BASELINE.json's other single-GPU configurations under the same clock (side legs, rank 0, N=1): UFM-Refine
                 518^2 batch 8 and UFM-Base 1036^2 batch 2 -- pairs/s, ms/step, per-family MFMA fractions (attention at N = 10 954).
+  default_res   the reference's class-default resolution (inference_resolution=None -> 560 x 420, base.py:89-90) at B = 8 on 1080 x 810 inputs (side leg).
   roofline.clock_ghz / frac_at_clock   the clock the chip holds under the dominant family (s_memtime / s_memrealtime stamps of the
                 diagnostic GEMM instantiations after 2 s of load) and `achieved` against the peak AT that clock.
 """
@@ -156,11 +157,11 @@ def order_line(line: dict, pairs_per_step: int) -> dict:
         if ps:
             summary["gemm_shape_frac"] = {t.replace(" (read-modify-write)", "").replace(" out", ""): r["frac"] for t, r in ps.items() if r["launches"] > 1}
     for k, v in line.items():
-        if k not in out and k not in ("kernels", "precise_mode", "roofline", "attention", "check_vs_oracle", "latency_b1_ms", "parity_mode", "end_to_end", "attention_share", "config4", "config5"):
+        if k not in out and k not in ("kernels", "precise_mode", "roofline", "attention", "check_vs_oracle", "latency_b1_ms", "parity_mode", "end_to_end", "attention_share", "config4", "config5", "default_res"):
             out[k] = v
     if pm is not None:
         out["precise_mode"] = pm
-    for k in ("config4", "config5", "parity_mode", "check_vs_oracle", "latency_b1_ms", "attention", "end_to_end", "attention_share", "roofline"):
+    for k in ("config4", "config5", "default_res", "parity_mode", "check_vs_oracle", "latency_b1_ms", "attention", "end_to_end", "attention_share", "roofline"):
         if k in line:
             out[k] = line[k]
     # compact repeat of the judged scalars, last
@@ -188,7 +189,7 @@ def order_line(line: dict, pairs_per_step: int) -> dict:
         cv = (kernels or {}).get("ufm_conv2d_nhwc_bf16x3", {})
         if "clock_ghz" in cv:
             summary["conv_clock_ghz"], summary["conv_frac_at_clock"] = round(cv["clock_ghz"], 3), round(cv["frac_at_clock"], 4)
-    for k in ("config4", "config5"):
+    for k in ("config4", "config5", "default_res"):
         if k in line:
             c = line[k]
             summary[k] = {"pairs_per_s": round(c["value"], 2), "ms_per_step": round(c["ms_per_step"], 2),
@@ -233,16 +234,25 @@ def side_config(ufm_amd, hip, which: str, res: int, batch: int, steps: int, micr
     at 518^2, batch 8; config 5 = UFM-Base at 1036^2 (5477-token encoder / 10 954-token joint attention), batch 2."""
     from ufm_amd.modules import init_weights_
 
+    in_hw = (res, res)
     if which == "refine":
         m = ufm_amd.UniFlowMatchClassificationRefinement(**ufm_amd.ufm_refine_config(resolution_wh=(res, res))).eval()
+    elif which == "default_res":
+        # the reference's class default: inference_resolution=None -> (560, 420) W x H (/root/reference/uniflowmatch/models/base.py:89-90), a
+        # 30 x 40 patch grid with the 518-native position embedding interpolated; inputs 1080 x 810 uint8 (antialiased resize on the GPU inside the step)
+        cfg = ufm_amd.ufm_base_config()
+        cfg.pop("inference_resolution")
+        m = ufm_amd.UniFlowMatchConfidence(**cfg).eval()
+        assert m.inference_resolution == [(560, 420)]
+        in_hw = (810, 1080)
     else:
         m = ufm_amd.UniFlowMatchConfidence(**ufm_amd.ufm_base_config(resolution_wh=(res, res))).eval()
     init_weights_(m, seed=0)
     m = m.to("cuda").set_numerics("fast")
     m.engine().micro_batches = micro_batches
     g = torch.Generator().manual_seed(4321)
-    s = torch.randint(0, 256, (batch, res, res, 3), dtype=torch.uint8, generator=g).cuda()
-    t = torch.randint(0, 256, (batch, res, res, 3), dtype=torch.uint8, generator=g).cuda()
+    s = torch.randint(0, 256, (batch, in_hw[0], in_hw[1], 3), dtype=torch.uint8, generator=g).cuda()
+    t = torch.randint(0, 256, (batch, in_hw[0], in_hw[1], 3), dtype=torch.uint8, generator=g).cuda()
     for _ in range(2):
         m.predict_correspondences_batched(s, t)
     torch.cuda.synchronize()
@@ -251,7 +261,9 @@ def side_config(ufm_amd, hip, which: str, res: int, batch: int, steps: int, micr
         m.predict_correspondences_batched(s, t)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - c0) / steps
-    out = {"workload": ("UFM-Refine" if which == "refine" else "UFM-Base") + f", random init, batch={batch} {res}x{res} synthetic pairs, 1xMI355X",
+    what = (f"class-default inference resolution 560x420 (30 x 40 patch grid), {in_hw[1]}x{in_hw[0]} uint8 synthetic pairs resized on the GPU" if which == "default_res"
+            else f"{res}x{res} synthetic pairs")
+    out = {"workload": ("UFM-Refine" if which == "refine" else "UFM-Base") + f", random init, batch={batch} {what}, 1xMI355X",
            "value": batch / dt, "unit": "pairs/s", "ms_per_step": 1e3 * dt, "steps": steps, "numerics": "fast"}
     summ, _records = instrumented_steps(lambda: m.predict_correspondences_batched(s, t), reps=2)
     fam = {}
@@ -758,6 +770,7 @@ def main():
         torch.cuda.empty_cache()
         line["config4"] = side_config(ufm_amd, hip, "refine", 518, 8, steps=6, micro_batches=args.micro_batches)
         line["config5"] = side_config(ufm_amd, hip, "base", 1036, 2, steps=4, micro_batches=args.micro_batches)
+        line["default_res"] = side_config(ufm_amd, hip, "default_res", 518, 8, steps=6, micro_batches=args.micro_batches)
 
     # ---- the clock the chip holds under the dominant kernel family (in-kernel stamps, diagnostic instantiations) ----
     if rank == 0 and world == 1 and args.numerics == "fast" and not args.no_clock and "roofline" in line:

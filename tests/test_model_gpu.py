@@ -307,6 +307,49 @@ def test_ufm_base_full_size_parity(env):
     assert e_fast_ac.mean().item() <= 1.5 * e_ac.mean().item() and e_fast_ac.max().item() <= 1.5 * e_ac.max().item()
 
 
+def test_ufm_base_class_default_resolution_full_size(env):
+    """VERDICT r5 item 6.  What `from_pretrained` gives a user who passes nothing: `inference_resolution=None` -> the class default
+    (560, 420) W x H (/root/reference/uniflowmatch/models/base.py:89-90) -- a NON-SQUARE 30 x 40 patch grid, 1 201 tokens per image, the
+    518-native position embedding interpolated 37^2 -> 30 x 40 at ViT-L dimensions, DPT maps of 120 x 160 ... 15 x 20 and a 420 x 560 head
+    output un-mapped to the 810 x 1080 input (scale 1080 / 560 = 810 / 420 = 1.93: one network-frame pixel is 1.93 source pixels, so the
+    1e-3 px gate of the network frame is 1.93e-3 px in the source frame).  B = 1, uint8 1080 x 810 inputs, UFM-Base dimensions.
+    "parity" and "precise" within the gate vs the fp32 CPU oracle; "fast" within 1.5x of the distance the reference's own bf16-autocast
+    policy (base.py:273) moves the oracle."""
+    ufm_amd, R = env
+    torch.manual_seed(0)
+    cfg_o, cfg_p = R.ufm_base_config(), ufm_amd.ufm_base_config()
+    cfg_o.pop("inference_resolution")  # -> the constructors' own default
+    cfg_p.pop("inference_resolution")
+    oracle = R.UFMRef(**cfg_o).eval()
+    R.init_weights_(oracle, 0)
+    prod = ufm_amd.UniFlowMatchConfidence(**cfg_p).eval()
+    assert prod.inference_resolution == [(560, 420)] and [tuple(r) for r in oracle.inference_resolution] == [(560, 420)]
+    prod.load_state_dict(oracle.state_dict(), strict=True)
+    prod = prod.to(DEV)
+    src, tgt = u8((1, 810, 1080, 3), 77), u8((1, 810, 1080, 3), 78)
+    o = oracle.predict_correspondences_batched(src, tgt)
+    assert o.flow.flow_output.shape == (1, 2, 810, 1080)
+    scale = 1080 / 560
+    for mode in ("parity", "precise"):
+        p = prod.set_numerics(mode).predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
+        df, dm, mx = compare(o, p)
+        print(f"UFM-Base class-default 420x560 (input 810x1080) {mode}: flow max-abs {df:.3g} px in the source frame (gate {1e-3 * scale:.3g}; range {mx:.3g}), mask {dm:.3g}")
+        assert df <= 1e-3 * scale and dm <= 1e-3, (mode, df, dm, mx)
+    pf = prod.set_numerics("fast").predict_correspondences_batched(src.to(DEV), tgt.to(DEV))
+    df2, dm2, mx = compare(o, pf)
+    pf_flow = pf.flow.flow_output.clone()  # (the next call on this engine may reuse the output workspace)
+    mean_abs = (o.flow.flow_output - pf_flow.cpu()).abs().mean().item()
+    oracle.autocast_bf16 = True
+    oa = oracle.predict_correspondences_batched(src, tgt)
+    oracle.autocast_bf16 = False
+    e_ac = (oa.flow.flow_output - o.flow.flow_output).abs()
+    print(f"UFM-Base class-default fast: flow max-abs {df2:.3g} mean-abs {mean_abs:.3g} (range {mx:.3g}), mask {dm2:.3g}; autocast-oracle vs fp32 oracle max {e_ac.max():.3g} mean {e_ac.mean():.3g}")
+    assert mean_abs <= 1.5 * e_ac.mean().item() and df2 <= 1.5 * e_ac.max().item(), (mean_abs, df2, e_ac.mean().item(), e_ac.max().item())
+    # the batch path at this resolution: two pairs = the one-pair results, bit for bit (odd token count 1201, non-square maps)
+    two = prod.predict_correspondences_batched(torch.cat([src, tgt]).to(DEV), torch.cat([tgt, src]).to(DEV))
+    assert torch.equal(two.flow.flow_output[:1], pf_flow)
+
+
 def test_second_weight_regime_outlier_channels_and_small_layerscale(env):
     """The fast-mode bound above rests on ONE weight statistic (random O(1) weights, LayerScale 1 +- 0.1).  A second, harsher one
     on a mid-size model (256-wide, 6 + 4 blocks, 154 x 154 px): LayerScale gammas of mixed sign and magnitude ~0.3 and four "massive activation" channels in the position embedding (x 25: the outlier channels trained ViTs carry
