@@ -1317,6 +1317,59 @@ def test_conv2d_bf16x3_8phase_bit_identical(hip, B, H, W, Cin, Cout, k, stride, 
 
 
 @pytest.mark.parametrize(
+    "B,H,W,Cin,Cout,act,nres,groups",
+    [
+        (8, 148, 148, 256, 256, 0, 1, 1),   # the heads' dominant layer (RCU conv2 + skip): 685 tiles, 24 windows per tile pair of super-tiles
+        (2, 148, 148, 96, 256, 0, 0, 1),    # Cin = 96: an ODD number of windows (9) -- the loop is entered at its second half
+        (3, 74, 74, 192, 256, 2, 2, 1),     # W = 74: two row ends per 128-pixel wave row; both residuals; output ReLU
+        (5, 37, 41, 64, 256, 0, 1, 1),      # non-square, W odd, H W = 1517: tiles straddle IMAGE boundaries (top / bottom rows voided per window)
+        (7, 19, 33, 32, 256, 0, 0, 1),      # Cin = 32: three windows (the minimum); (H - 2) W = 561; ragged last tile
+        (1, 64, 32, 64, 512, 0, 0, 1),      # W = 32 (the minimum: one row end per fragment), two cout tiles
+        (4, 40, 48, 128, 256, 0, 1, 2),     # a grouped launch (the two DPT heads in one grid): per-group windows, ragged per-group tiles
+    ],
+)
+def test_conv2d_bf16x3_halo_bit_identical(hip, B, H, W, Cin, Cout, act, nres, groups):
+    """Round 6: conv_bf16x3_halo.hip -- the 8-phase 3x3 kernel with the input staged once per FILTER ROW (a row-window halo tile) instead of
+    once per tap, row borders voided when a window is staged (out-of-range buffer offsets write zeros to LDS), column borders zeroed in
+    the fragment registers.  Same K order, same products: bit-identical to the gather form of the 8-phase kernel (variant HALO = 1:
+    bit 5), at every tile height (nf 5..8), and to the plain 128-row kernels with the serial epilogue (variant 19), through the
+    reference's DPT convolution shapes (/root/reference/uniflowmatch/models/ufm.py:243-289) and the awkward ones: odd window counts,
+    tiles across image boundaries, W = 32, ragged tiles, groups."""
+    lib = hip.lib()
+    G = groups
+    x = split(nhwc(rnd(G * B, Cin, H, W, seed=1))).to(DEV)
+    w = split(rnd(G * Cout, 3, 3, Cin, seed=2, scale=(Cin * 9) ** -0.5)).to(DEV)
+    b = rnd(G * Cout, seed=3, scale=0.1).to(DEV)
+    oshape = (2, G * B, H, W, Cout)
+    res = [split(rnd(G * B, H, W, Cout, seed=10 + i)).to(DEV) for i in range(nres)] + [None, None]
+    zero = torch.zeros(256, device=DEV)
+    outs = {}
+    HALO_OFF = 1 << 5
+    variants = (19, 2 | HALO_OFF, 2, 0, 2 | (5 << 8), 2 | (6 << 8), 2 | (7 << 8), 2 | (7 << 8) | HALO_OFF)
+    try:
+        for variant in variants:
+            assert lib.ufm_debug_set_conv_variant(variant) == 0
+            out = torch.full(oshape, 7.0, device=DEV, dtype=torch.bfloat16)
+            orl = torch.full(oshape, 7.0, device=DEV, dtype=torch.bfloat16)
+            hip.conv2d_x3(x, B, H, W, Cin, w, Cout, 3, 3, 1, 1, out, zero, bias=b, act=act, res1=res[0], res2=res[1], out_relu=orl, groups=G)
+            outs[variant] = (out.view(torch.int16).clone(), orl.view(torch.int16).clone())
+    finally:
+        lib.ufm_debug_set_conv_variant(0)
+    for v in variants[1:]:
+        assert torch.equal(outs[19][0], outs[v][0]), (v, int((outs[19][0] != outs[v][0]).sum()))
+        assert torch.equal(outs[19][1], outs[v][1]), v
+    # ... and the numbers are a convolution: against the fp64 statement on the split operands (first group)
+    xs, ws = unsplit(x.cpu())[:B].permute(0, 3, 1, 2).double(), unsplit(w.cpu())[:Cout].permute(0, 3, 1, 2).double()
+    ref = F.conv2d(xs, ws, b[:Cout].cpu().double(), padding=1)
+    if act == 2:
+        ref = torch.relu(ref)
+    for r in res[:nres]:
+        ref = ref + unsplit(r.cpu())[:B].permute(0, 3, 1, 2).double()
+    got = unsplit(outs[2][0].view(torch.bfloat16).cpu())[:B].permute(0, 3, 1, 2).double()
+    assert (got - ref).abs().max().item() <= 4e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize(
     "B,H,W,Cin,Cout,k,stride,pad,act,nres,shuffle,shared",
     [
         (2, 37, 37, 256, 256, 3, 1, 1, 0, 2, 0, False),   # small grid: 64x64 tiles / deep ring

@@ -345,6 +345,16 @@ static void launch_conv_x3(const ConvX3Args& p_in, int passes, hipStream_t strea
     const int tile_n = 256, tile_m = 256;
     const bool ok8 = Cout % 256 == 0 && KH * KW * (Cin / 32) >= 2 && p.in_plane < (1ll << 31) && p.w_plane < (1ll << 31);
     const long long t8 = ((M + tile_m - 1) / tile_m) * (Cout / tile_n) * G;  // 8-phase tiles of all groups
+    // Round 6: wherever the 8-phase kernel is chosen, a 3x3 / stride 1 / pad 1 / zero-padding layer runs on its row-window halo form
+    // (conv_bf16x3_halo.hip: the input staged once per filter row, not once per tap; bit-identical).  Lab field HALO = 1: never (A/B, tests).
+    const bool halo = KH == 3 && KW == 3 && p.stride == 1 && p.pad == 1 && !p.replicate && !p.relu_in && p.Ho == p.H && p.Wo == p.W && passes == 3 &&
+                      p.W >= 32 && (long long)(p.H - 2) * p.W >= 272 &&   // one column border per 16-pixel fragment; image boundaries further apart than a window + two rows
+                      p.in_plane < (1ll << 29) && p.w_plane < (1ll << 29) &&  // 32-bit buffer offsets of both planes below 2^31 bytes
+                      lab_get(g_conv_variant_all, conv_lab::HALO) != 1 && !p.ablate;
+    auto launch8 = [&](const ConvX3Args& q, int nf) {
+        if (halo) ufm_launch_conv_x3_halo(q, stream, nf);
+        else ufm_launch_conv_x3_8ph(q, stream, nf);
+    };
     // 256 px x 128 cout pair tile (round 5): Cout a multiple of 128 but not of 256 (the heads' p_conv1, 296^2 x 256 -> 128) on grids of at
     // least one workgroup per CU.  g_conv_variant 4 = wherever it applies (tests), 1 / 3 = never.
     const bool okp = Cout % 128 == 0 && KH * KW * (Cin / 32) >= 2 && p.in_plane < (1ll << 31) && p.w_plane < (1ll << 31) && passes == 3 && S == 1;
@@ -354,7 +364,7 @@ static void launch_conv_x3(const ConvX3Args& p_in, int passes, hipStream_t strea
     } else if (passes == 1 || S > 1) {  // (split-K lives in the 128- / 64-row kernels: its layers are the small maps the 8-phase tile never fits)
         launch128(p);
     } else if (ok8 && g_conv_variant == 2) {
-        ufm_launch_conv_x3_8ph(p, stream, nf_pin >= 5 && nf_pin <= 8 ? nf_pin : 8);
+        launch8(p, nf_pin >= 5 && nf_pin <= 8 ? nf_pin : 8);
     } else if (ok8 && g_conv_variant == 0 && t8 >= ufm_device_cu_count() / 2 && KH * KW * (Cin / 32) >= 16) {  // (variants 1 and 3 never take this branch)
         // Measured per shape (tools/lab/conv_rounds.py, profiles/r03/conv_rounds.log): a last partial round of at least half
         // the chip is cheaper on the 8-phase kernel than on the 128-row kernels (148^2 RCU, 684 tiles: 485 vs 518 us; 74^2 RCU,
@@ -392,12 +402,12 @@ static void launch_conv_x3(const ConvX3Args& p_in, int passes, hipStream_t strea
             hybrid = (double)full + 0.6 + 0.35 * (frac128 < 1.0 ? frac128 : 1.0) < best;
         }
         if (!hybrid) {
-            ufm_launch_conv_x3_8ph(p, stream, best_nf);
+            launch8(p, best_nf);
         } else {
             ConvX3Args lead = p, rest = p;
             lead.M = (int)m_main;
             rest.m_begin = (int)m_main;
-            ufm_launch_conv_x3_8ph(lead, stream);
+            launch8(lead, 8);
             launch128(rest);
         }
     } else {

@@ -239,4 +239,7 @@ static __device__ __forceinline__ void conv_x3_epilogue(const ConvX3Args& p, f32
 // conv_bf16x3_8ph.hip: 8-phase kernels, 256 px x 256 cout (Cout % 256 == 0) or 512 px x 128 cout (Cout % 128 == 0); 32-bit operand offsets
 // conv_bf16x3_pair.hip: 256 px x 128 cout, four waves, two resident workgroups per CU (Cout % 128 == 0, at least 2 K-tiles, 32-bit operand offsets)
 int ufm_launch_conv_x3_pair(const ConvX3Args& p, hipStream_t stream);
+// conv_bf16x3_halo.hip (round 6): the 8-phase 256-cout kernel for 3x3 / stride 1 / pad 1 / zero padding with the input staged once per filter
+// row (a row-window halo tile) instead of once per tap; same tile heights (32 nf pixels), bit-identical
+int ufm_launch_conv_x3_halo(const ConvX3Args& p, hipStream_t stream, int nf = 8);
 int ufm_launch_conv_x3_8ph(const ConvX3Args& p, hipStream_t stream, int nf = 8);  // nf = 16-row fragments per wave row (5..8): tiles of 32 nf pixels
