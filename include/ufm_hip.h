@@ -46,6 +46,7 @@ const char* ufm_built_arch(void);
 /* "split" fp32-class format: two bf16 planes [2][rows][C]; plane 0 = hi = bf16(x), plane 1 = lo =
  * bf16(x - hi); the pointer addresses plane 0 and plane 1 follows at rows*C elements. */
 #define UFM_BF16X2 2
+#define UFM_BF16X2_IL 3 /* split bf16, INTERLEAVED per 32-channel chunk: [rows][C / 32][hi 32 | lo 32] (round 6; ufm_layernorm output, ufm_gemm_bf16x3_il operand) */
 
 /* ---- activation codes ---- */
 #define UFM_ACT_NONE 0
@@ -204,7 +205,8 @@ int ufm_warp_bilinear(const void* target, int tgt_dtype, int Ht, int Wt, const f
  * Output row i is computed from input row (row_index ? row_index[i] : i): this is how the cls
  * token is dropped and views are re-ordered (models/ufm.py:313, :596-615) without a copy.
  * ===================================================================================== */
-/* out_dtype: UFM_F32, UFM_BF16 or UFM_BF16X2 (lo plane at out + rows_out*ldo elements). */
+/* out_dtype: UFM_F32, UFM_BF16, UFM_BF16X2 (lo plane at out + rows_out*ldo elements) or UFM_BF16X2_IL (ufm_layernorm only, D % 256 == 0:
+ * [rows_out][ldo / 32][hi 32 | lo 32], i.e. 2 ldo elements per row; the operand format of ufm_gemm_bf16x3_il). */
 int ufm_layernorm(const float* x, int ldx, const int32_t* row_index, int rows_out, int D,
                   const float* weight, const float* bias, float eps, void* out, int out_dtype,
                   int ldo, void* stream);
@@ -346,7 +348,16 @@ long long ufm_conv_x3_splitk_ws_bytes(int groups, int B, int H, int W, int Cin, 
 int ufm_gemm_bf16x3(const uint16_t* A, const uint16_t* W, int M, int N, int K, const float* bias, int act,
                     const float* gamma, const float* res, void* out, int out_dtype, const uint16_t* zero_page,
                     void* stream);
+/* Round 6: the same Linear layer on INTERLEAVED split operands -- A: [M][K / 32][hi 32 | lo 32] (ufm_layernorm with out_dtype UFM_BF16X2_IL
+ * writes it), W: [N][K / 32][hi 32 | lo 32] (interleaved at pack time) -- so that every LDS-DMA row of the kernel's loop is one whole 128-byte
+ * line.  Same K order, same products, same epilogues and output formats as ufm_gemm_bf16x3: bit-identical results.  N % 256 == 0, K % 32 == 0,
+ * K >= 64; out_dtype additionally UFM_BF16X2_IL (the split output interleaved too: fc1 -> fc2).  Serves all four nn.Linear call sites of a block
+ * (Attention.qkv / proj, Mlp.fc1 / fc2) in numerics "precise": LayerNorm, ufm_attention_bf16x3_il and the fc1 epilogue write the operands. */
+int ufm_gemm_bf16x3_il(const uint16_t* A, const uint16_t* W, int M, int N, int K, const float* bias, int act, const float* gamma,
+                       const float* res, void* out, int out_dtype, const uint16_t* zero_page, void* stream);
 int ufm_attention_bf16x3(const uint16_t* qkv, uint16_t* out, int B, int N, int H, float scale, void* stream);
+/* Round 6: the same attention with O stored INTERLEAVED (UFM_BF16X2_IL: [B*N][H*64 / 32][hi 32 | lo 32]) -- the A operand of ufm_gemm_bf16x3_il. */
+int ufm_attention_bf16x3_il(const uint16_t* qkv, uint16_t* out, int B, int N, int H, float scale, void* stream);
 
 /* Bilinear resize, align_corners=True, NHWC fp32 ([U] FeatureFusionBlock x2 upsample,
  * DPTRegressionProcessor interpolate-to-target).  src = dst*(in-1)/(out-1).  crop_h/crop_w > 0:

@@ -1102,6 +1102,79 @@ def test_gemm_bf16x3(hip, M, N, K, act, use_gamma, use_res, split_out):
         assert torch.equal(out2.view(torch.int16), out.view(torch.int16))
 
 
+@pytest.mark.parametrize(
+    "M,N,K,act,use_gamma,use_res,split_out",
+    [
+        (300, 256, 64, 0, False, False, True),            # two K-tiles: prologue + tail waits only
+        (2 * 1370, 3072, 1024, 0, True, False, True),     # encoder QKV (Q pre-scale as gamma)
+        (1370, 4096, 1024, 1, False, False, True),        # encoder fc1: GELU + split store
+        (8 * 1369 + 5, 2304, 768, 0, True, False, True),  # info-sharing QKV, ragged rows
+        (2738, 3072, 768, 1, False, False, True),         # info-sharing fc1
+        (513, 1024, 4096, 0, True, True, False),          # fc2 shape: fp32 read-modify-write (not fed by a LayerNorm in the engine; the kernel supports it)
+    ],
+)
+def test_gemm_bf16x3_interleaved_operands_are_bitwise_the_planar_form(hip, M, N, K, act, use_gamma, use_res, split_out):
+    """Round 6: ufm_gemm_bf16x3_il reads A and W INTERLEAVED per 32-channel chunk ([rows][K / 32][hi 32 | lo 32]: every
+    LDS-DMA row of the 8-phase loop one whole 128-byte line) -- same K order, same three products per fragment pair, same epilogues as
+    ufm_gemm_bf16x3 on the planar planes: bit-identical outputs, at every tile height (the Linear layers of
+    /root/reference/uniflowmatch/models/ufm.py:187,193 in numerics "precise")."""
+    lib = hip.lib()
+    A = split(rnd(M, K, seed=1)).to(DEV)
+    W = split(rnd(N, K, seed=2, scale=K**-0.5)).to(DEV)
+    Ai, Wi = hip.interleave_split(A), hip.interleave_split(W)
+    assert Ai.shape == (M, K // 32, 2, 32) and torch.equal(Ai[5, 1, 1], A[1, 5, 32:64])
+    bias = rnd(N, seed=3, scale=0.1).to(DEV)
+    gamma = (1 + rnd(N, seed=4, scale=0.1)).to(DEV) if use_gamma else None
+    res = rnd(M, N, seed=5).to(DEV) if use_res else None
+    zero = torch.zeros(256, device=DEV)
+
+    def run(fn, a, w):
+        if split_out:
+            o = torch.full((2, M, N), 7.0, device=DEV, dtype=torch.bfloat16)
+            fn(a, w, M, N, K, o, zero, bias=bias, act=act, gamma=gamma)
+            return o.view(torch.int16).clone()
+        o = res.clone()
+        fn(a, w, M, N, K, o, zero, bias=bias, act=act, gamma=gamma, res=o)
+        return o.view(torch.int32).clone()
+
+    want = run(hip.gemm_x3, A, W)
+    try:
+        for variant in (0, 2 | (5 << 8), 2 | (6 << 8), 2 | (7 << 8), 2 | (8 << 8), 16):  # (16: the serial per-pass epilogue)
+            assert lib.ufm_debug_set_conv_variant(variant) == 0
+            got = run(hip.gemm_x3_il, Ai, Wi)
+            assert torch.equal(got, want), (variant, int((got != want).sum()))
+            if split_out:  # ... and with the split OUTPUT interleaved too (UFM_BF16X2_IL: fc1 -> fc2): the same values at other addresses
+                o = torch.full((M, N // 32, 2, 32), 7.0, device=DEV, dtype=torch.bfloat16)
+                hip.gemm_x3_il(Ai, Wi, M, N, K, o, zero, bias=bias, act=act, gamma=gamma)
+                assert torch.equal(o.view(torch.int16), hip.interleave_split(want.view(torch.bfloat16)).view(torch.int16)), variant
+    finally:
+        lib.ufm_debug_set_conv_variant(0)
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 1370, 16), (1, 2738, 12), (3, 77, 4)])
+def test_attention_bf16x3_interleaved_output(hip, B, N, H):
+    """ufm_attention_bf16x3_il: O stored [B N][H 64 / 32][hi 32 | lo 32] (the proj Linear's operand in numerics "precise") -- bitwise the
+    planar output of ufm_attention_bf16x3, re-laid (SDPA under /root/reference/uniflowmatch/models/base.py:272-274)."""
+    qkv = split(rnd(B * N, 3 * H * 64, seed=1)).to(DEV)
+    planar = torch.full((2, B * N, H * 64), 7.0, device=DEV, dtype=torch.bfloat16)
+    hip.attention_x3(qkv, planar, B, N, H, 0.125)
+    il = torch.full((B * N, H * 2, 2, 32), 7.0, device=DEV, dtype=torch.bfloat16)
+    hip.attention_x3(qkv, il, B, N, H, 0.125, out_interleaved=True)
+    assert torch.equal(il.view(torch.int16), hip.interleave_split(planar).view(torch.int16))
+
+
+@pytest.mark.parametrize("rows,D", [(37, 256), (1370, 1024), (2738, 768)])
+def test_layernorm_interleaved_split_output(hip, rows, D):
+    """ufm_layernorm with out_dtype UFM_BF16X2_IL: the same (hi, lo) values as the planar split output, laid out [row][D / 32][hi 32 | lo 32]."""
+    x = rnd(rows, D, seed=1).to(DEV)
+    w, b = (1 + rnd(D, seed=2, scale=0.1)).to(DEV), rnd(D, seed=3, scale=0.1).to(DEV)
+    planar = torch.full((2, rows, D), 7.0, device=DEV, dtype=torch.bfloat16)
+    hip.layernorm(x, D, None, rows, D, w, b, 1e-6, planar, split=True)
+    il = torch.full((rows, D // 32, 2, 32), 7.0, device=DEV, dtype=torch.bfloat16)
+    hip.layernorm(x, D, None, rows, D, w, b, 1e-6, il, split=True, interleaved=True)
+    assert torch.equal(il.view(torch.int16), hip.interleave_split(planar).view(torch.int16))
+
+
 @pytest.mark.parametrize("M,N,K,use_res,act", [(512, 256, 128, True, 0), (512, 256, 128, False, 0), (512, 256, 128, False, 2)])
 def test_gemm_bf16x3_nan_in_is_nan_out_in_the_grouped_epilogue(hip, M, N, K, use_res, act):
     """the grouped (round 5) epilogue applied 'no activation' as fmaxf(v, -inf) -- fmaxf returns its non-NaN operand, so a NaN

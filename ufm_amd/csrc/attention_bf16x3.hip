@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(const uint16_t* __restr
 
 // attention_bf16x3_pw.hip: the round-5 kernel (one wave per SIMD, two q-blocks per wave, LDS-DMA rings); bitwise this file's kernel
 int ufm_launch_attn_x3_pw(const uint16_t* q, int ldq, long long q_plane, const uint16_t* k, const uint16_t* v, int ldkv, long long in_plane,
-                          uint16_t* out, int ldo, long long out_plane, int B, int Nq, int Nk, int H, float c, hipStream_t stream, int waves);
+                          uint16_t* out, int ldo, long long out_plane, int B, int Nq, int Nk, int H, float c, hipStream_t stream, int waves, int out_il = 0);
 int ufm_attn_x3_use_old();  // attention_bf16.hip: ufm_debug_set_attn_variant bit 1
 int ufm_attn_x3_waves();    // bit 2: eight waves per workgroup instead of four
 
@@ -265,6 +265,21 @@ extern "C" int ufm_attention_bf16x3(const uint16_t* qkv, uint16_t* out, int B, i
     hipLaunchKernelGGL(attn_x3_kernel, grid, block, 0, (hipStream_t)stream, qkv, 3 * H * 64, rows * 3 * H * 64, qkv + H * 64, qkv + 2 * H * 64, 3 * H * 64,
                        rows * 3 * H * 64, out, H * 64, rows * H * 64, N, N, H, scale * 1.44269504088896340736f);
     UFM_CHECK_LAUNCH("ufm_attention_bf16x3");
+    return UFM_OK;
+}
+
+// ufm_attention_bf16x3 with the output stored INTERLEAVED ([B N][H 64 / 32][hi 32 | lo 32], UFM_BF16X2_IL): the A operand of ufm_gemm_bf16x3_il
+// (the proj Linear of numerics "precise").  Same kernel, same values as ufm_attention_bf16x3, other store addresses.
+extern "C" int ufm_attention_bf16x3_il(const uint16_t* qkv, uint16_t* out, int B, int N, int H, float scale, void* stream) {
+    UFM_REQUIRE(qkv && out, "ufm_attention_bf16x3_il: null pointer");
+    UFM_REQUIRE(B > 0 && N > 0 && H > 0 && (int64_t)((N + QB - 1) / QB) * H * B < (1ll << 31), "ufm_attention_bf16x3_il: bad shape B=%d N=%d H=%d", B, N, H);
+    UFM_REQUIRE(scale > 0.0f, "ufm_attention_bf16x3_il: scale must be positive");
+    UFM_REQUIRE(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 8) == 0, "ufm_attention_bf16x3_il: misaligned pointer");
+    UFM_REQUIRE(!ufm_attn_x3_use_old() && (long long)N * 3 * H * 64 * 2 < (1ll << 31), "ufm_attention_bf16x3_il: the interleaved output exists in the LDS-DMA kernel only (variant bit 1 clear, N * 3 H * 128 B < 2 GiB)");
+    const long long rows = (long long)B * N;
+    ufm_launch_attn_x3_pw(qkv, 3 * H * 64, rows * 3 * H * 64, qkv + H * 64, qkv + 2 * H * 64, 3 * H * 64, rows * 3 * H * 64, out, H * 64, rows * H * 64, B, N, N, H,
+                          scale * 1.44269504088896340736f, (hipStream_t)stream, ufm_attn_x3_waves(), 1);
+    UFM_CHECK_LAUNCH("ufm_attention_bf16x3_il");
     return UFM_OK;
 }
 

@@ -51,7 +51,7 @@ __device__ __forceinline__ unsigned lds_addr_of(const char* p) { return (unsigne
 template <int NW>
 __global__ __launch_bounds__(NW * 64, 8 / NW) void attn_x3_pw_kernel(const uint16_t* __restrict__ qp_, int ldq, long long q_plane,
                                                             const uint16_t* __restrict__ kp_, const uint16_t* __restrict__ vp_, int ldkv, long long in_plane,
-                                                            uint16_t* __restrict__ out, int ldo, long long out_plane, int Nq, int N, int H, float c) {
+                                                            uint16_t* __restrict__ out, int ldo, long long out_plane, int Nq, int N, int H, float c, int out_il) {
     __shared__ __attribute__((aligned(16))) char smem[X3PW_LDS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -310,7 +310,10 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attn_x3_pw_kernel(const uint1
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     if (q < Nq) {
-        uint16_t* orow = out + ((size_t)b * Nq + q) * ldo + head * 64 + 4 * hh;
+        // out_il (round 6): O stored INTERLEAVED per 32-channel chunk, [row][ldo / 32][hi 32 | lo 32] -- the A operand of ufm_gemm_bf16x3_il (proj);
+        // a head is two chunks (dt = 0, 1): the same values at other addresses
+        uint16_t* orow = out_il ? out + ((size_t)b * Nq + q) * (2 * ldo) + head * 128 + 4 * hh : out + ((size_t)b * Nq + q) * ldo + head * 64 + 4 * hh;
+        const long long dstep = out_il ? 64 : 32, lo_off = out_il ? 32 : out_plane;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -323,8 +326,8 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attn_x3_pw_kernel(const uint1
                 hi[2] = __uint_as_float(h1 << 16), hi[3] = __uint_as_float(h1 & 0xffff0000u);
                 u32x2 pkh = {h0, h1};
                 u32x2 pkl = {pack_bf16x2(v[0] - hi[0], v[1] - hi[1]), pack_bf16x2(v[2] - hi[2], v[3] - hi[3])};
-                *(u32x2*)(orow + dt * 32 + 8 * g) = pkh;
-                *(u32x2*)(orow + out_plane + dt * 32 + 8 * g) = pkl;
+                *(u32x2*)(orow + dt * dstep + 8 * g) = pkh;
+                *(u32x2*)(orow + lo_off + dt * dstep + 8 * g) = pkl;
             }
     }
 }
@@ -334,10 +337,10 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attn_x3_pw_kernel(const uint1
 // q / k / v: first element of head 0 of batch item 0 (hi plane); the lo planes follow q_plane / in_plane / out_plane elements behind.
 // The host has checked shapes, alignment and that one batch item's K / V rows fit a 32-bit byte offset.
 int ufm_launch_attn_x3_pw(const uint16_t* q, int ldq, long long q_plane, const uint16_t* k, const uint16_t* v, int ldkv, long long in_plane,
-                          uint16_t* out, int ldo, long long out_plane, int B, int Nq, int Nk, int H, float c, hipStream_t stream, int waves) {
+                          uint16_t* out, int ldo, long long out_plane, int B, int Nq, int Nk, int H, float c, hipStream_t stream, int waves, int out_il) {
     const int nw = waves == 8 ? 8 : 4;
     dim3 grid(((Nq + nw * 32 - 1) / (nw * 32)) * H * B), block(nw * 64);
-    if (nw == 8) hipLaunchKernelGGL(attn_x3_pw_kernel<8>, grid, block, 0, stream, q, ldq, q_plane, k, v, ldkv, in_plane, out, ldo, out_plane, Nq, Nk, H, c);
-    else hipLaunchKernelGGL(attn_x3_pw_kernel<4>, grid, block, 0, stream, q, ldq, q_plane, k, v, ldkv, in_plane, out, ldo, out_plane, Nq, Nk, H, c);
+    if (nw == 8) hipLaunchKernelGGL(attn_x3_pw_kernel<8>, grid, block, 0, stream, q, ldq, q_plane, k, v, ldkv, in_plane, out, ldo, out_plane, Nq, Nk, H, c, out_il);
+    else hipLaunchKernelGGL(attn_x3_pw_kernel<4>, grid, block, 0, stream, q, ldq, q_plane, k, v, ldkv, in_plane, out, ldo, out_plane, Nq, Nk, H, c, out_il);
     return 0;
 }

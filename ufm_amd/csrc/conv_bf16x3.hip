@@ -304,6 +304,21 @@ static void launch_conv_x3(const ConvX3Args& p_in, int passes, hipStream_t strea
     const int Cout = p.Cout, KH = p.KH, KW = p.KW, Cin = p.Cin;
     const long long M = p.M;
     const int S = p.splitk;
+    if (p.il) {  // interleaved operands: the 8-phase Linear form only; tile height by the cost model below (no hybrid: the 128-row kernels read planes)
+        const long long ncu = ufm_device_cu_count();
+        const bool throughput = lab_get(g_conv_variant_all, conv_lab::CU_TIME) || (ufm_stream_is_concurrent(stream) && !lab_get(g_conv_variant_all, conv_lab::LATENCY));
+        const bool only8 = M >= 8192 && throughput;
+        double best = 1e30;
+        int best_nf = 8;
+        for (int nf = 8; nf >= (only8 ? 8 : 5); --nf) {
+            const long long t = ((M + 32 * nf - 1) / (32 * nf)) * (Cout / 256);
+            const double c = (double)((t + ncu - 1) / ncu) * (0.65 + 0.35 * nf / 8.0);
+            if (c < best - 1e-9) best = c, best_nf = nf;
+        }
+        if (nf_pin >= 5 && nf_pin <= 8) best_nf = nf_pin;
+        ufm_launch_gemm_x3_il_8ph(p, stream, best_nf);
+        return;
+    }
     // Kernel choice.  Cout % 256 == 0 and a grid that fills the chip: the 256x256 8-phase kernel on the leading pixels
     // that make whole rounds of 256 CUs, the 128-row kernel on the rest (g_conv_variant: 0 auto, 1 = 128-row kernels
     // only, 2 = 8-phase on everything it accepts -- tests/tools).
@@ -498,5 +513,33 @@ extern "C" int ufm_gemm_bf16x3(const uint16_t* A, const uint16_t* W, int M, int 
     p.groups = 1, p.Mg = M, p.splitk = 1;
     launch_conv_x3(p, 3, (hipStream_t)stream);
     UFM_CHECK_LAUNCH("ufm_gemm_bf16x3");
+    return UFM_OK;
+}
+
+// The same Linear layer on INTERLEAVED split operands (round 6): A [M][K / 32][hi 32 | lo 32], W [N][K / 32][hi 32 | lo 32] -- every LDS-DMA row of
+// the 8-phase loop is then one whole 128-byte line instead of two 64-byte halves a plane apart.  Written by ufm_layernorm (out_dtype
+// UFM_BF16X2_IL); weights interleaved at pack time.  Outputs as ufm_gemm_bf16x3 (planar split or fp32).  N % 256 == 0, K % 32 == 0, K >= 64.
+extern "C" int ufm_gemm_bf16x3_il(const uint16_t* A, const uint16_t* W, int M, int N, int K, const float* bias, int act,
+                                  const float* gamma, const float* res, void* out, int out_dtype, const uint16_t* zero_page,
+                                  void* stream) {
+    UFM_REQUIRE(A && W && out && zero_page, "ufm_gemm_bf16x3_il: null pointer");
+    UFM_REQUIRE(M > 0 && N > 0 && K > 0, "ufm_gemm_bf16x3_il: bad shape M=%d N=%d K=%d", M, N, K);
+    UFM_REQUIRE(K % BK == 0 && K >= 2 * BK, "ufm_gemm_bf16x3_il: K=%d must be a multiple of %d and at least %d", K, BK, 2 * BK);
+    UFM_REQUIRE(N % 256 == 0, "ufm_gemm_bf16x3_il: N=%d must be a multiple of 256 (the 8-phase tile)", N);
+    UFM_REQUIRE(out_dtype == UFM_F32 || out_dtype == UFM_BF16X2 || out_dtype == UFM_BF16X2_IL, "ufm_gemm_bf16x3_il: out_dtype must be UFM_F32, UFM_BF16X2 or UFM_BF16X2_IL");
+    UFM_REQUIRE(out_dtype == UFM_F32 || !res, "ufm_gemm_bf16x3_il: the fp32 residual needs an fp32 output");
+    UFM_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)out % 16) == 0, "ufm_gemm_bf16x3_il: misaligned pointer");
+    UFM_REQUIRE((long long)M * K < (1ll << 30) && (long long)N * K < (1ll << 30) && (long long)M * N < (1ll << 31), "ufm_gemm_bf16x3_il: problem too large");
+    ConvX3Args p{A, W, bias, nullptr, nullptr, zero_page, out_dtype != UFM_F32 ? (uint16_t*)out : nullptr, nullptr,
+                 (long long)M * K, (long long)N * K, (long long)M * N,
+                 1, 1, M, K, N, 1, 1, 1, 0, 1, M, M, 0, act, 0, N, 0};
+    p.gamma = gamma;
+    p.res_f32 = res;
+    p.out_f32 = out_dtype == UFM_F32 ? (float*)out : nullptr;
+    p.groups = 1, p.Mg = M, p.splitk = 1;
+    p.il = 1;
+    p.out_il = out_dtype == UFM_BF16X2_IL;
+    launch_conv_x3(p, 3, (hipStream_t)stream);
+    UFM_CHECK_LAUNCH("ufm_gemm_bf16x3_il");
     return UFM_OK;
 }

@@ -38,9 +38,14 @@ struct TapIter {  // walks the K-tiles of one half-tile kind: channel-chunk oute
 // whole rounds of the chip.  (Round 5 also tried the phase's 24 MFMAs product-major over its eight accumulators instead of three
 // per accumulator back to back: neutral, 478.7 vs 479.2 us on the 148^2 layer, tools/lab/conv_stamps.py -- not kept.)
 // ABL: timing ablations of the loop (ConvX3Args::ablate; a diagnostic instantiation of its own, so that the stamped kernel stays the shipped loop)
-template <int WR, int WC, bool STAMP = false, int NF = 8, bool ABL = false>
+// IL (round 6): the Linear form on INTERLEAVED split operands -- A [M][K / 32][hi 32 | lo 32], W [N][K / 32][hi 32 | lo 32] -- so that every
+// LDS-DMA row is a whole 128-byte line (8 lanes x 16 B: the hi and the lo half of one 32-channel chunk of one row) instead of two 64-byte
+// halves 2 M K bytes apart.  LDS half-tile = [128 rows][128 B], 16-byte chunk c = 4 plane + fq stored at position c ^ (row & 7) (the bf16
+// GEMM's layout, with the planes in the place of its two k-substeps).  Same K order, same products: bit-identical to the planar form.
+template <int WR, int WC, bool STAMP = false, int NF = 8, bool ABL = false, bool IL = false>
 __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
     static_assert(WR * WC == 8, "eight waves");
+    static_assert(!IL || (WR == 2 && !ABL), "the interleaved form is built for the 2 x 4 layout");
     static_assert(NF >= 5 && NF <= 8 && (NF == 8 || WR == 2), "NF");
     constexpr int RW = 16 * NF;  // pixel rows of one wave row
     GemmStamps stamps;  // (diagnostic instantiation only: the shipped kernel executes no stamp)
@@ -97,6 +102,23 @@ __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
         const int bcol = (wlr >> 5) * 64 + h * 32 + (wlr & 31);     // W half h: couts nh = h of every wave column
         w_src[h] = (unsigned)(n0 + bcol) * ktot + w_chunk;
     }
+    // IL: piece = 8 rows x 128 B; wave w stages pieces w and 8 + w of every half-tile; lane (l >> 3, l & 7) = row, 16-byte position
+    unsigned xil_src[2][2], wil_src[2][2];  // [half][piece]: element offsets
+    if constexpr (IL) {
+        const int prow = lane >> 3, ppos = lane & 7;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int lr = (i * 8 + wave) * 8 + prow;  // row of the half-tile, 0..127
+            const unsigned chunk = (unsigned)((ppos ^ (lr & 7)) * 8);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int brow = (lr >> 6) * RW + h * 64 + (lr & 63);
+                const int bcol = (lr >> 5) * 64 + h * 32 + (lr & 31);
+                xil_src[h][i] = (unsigned)min(m0 + brow, p.M - 1) * (unsigned)(2 * p.Cin) + chunk;
+                wil_src[h][i] = (unsigned)(n0 + bcol) * (unsigned)(2 * p.Cin) + chunk;
+            }
+        }
+    }
     TapIter it[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     auto stage = [&](auto kind, int tile) {  // kind: 0 W-lo, 1 X-lo, 2 W-hi, 3 X-hi ; issues this kind's NEXT K-tile
         constexpr int KIND = decltype(kind)::value;
@@ -110,6 +132,15 @@ __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
                 if (++ti.tap == ntaps) ti.tap = 0, ti.kh = 0, ti.kw = 0, ti.c0 += 32;
                 return;
             }
+        }
+        if constexpr (IL) {  // 1x1 on interleaved operands: K-tile = chunk c0 / 32 = 64 elements [hi 32 | lo 32] of every row
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint16_t* src = (KIND & 1) ? in_g + (xil_src[H][i] + (unsigned)(2 * ti.c0)) : w_g + (wil_src[H][i] + (unsigned)(2 * ti.c0));
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(base + (i * 8 + wave) * 1024), 16, 0, 0);
+            }
+            ti.c0 += 32;
+            return;
         }
         if (KIND & 1) {
 #pragma unroll
@@ -151,6 +182,15 @@ __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
         w_off[j] = r * 64 + ((fq ^ swz(r)) << 4);
     }
 
+    // IL: row r of a half-tile at r * 128 B; plane pl, k-quarter fq at 16-byte position (4 pl + fq) ^ (r & 7); (r & 7) = fr & 7 for every fragment
+    int xil_off[2], wil_off[2];  // [plane]: fragment 0 of this wave; fragment i: + i * 2048
+    if constexpr (IL) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            xil_off[pl] = (wr * 64 + fr) * 128 + (((4 * pl + fq) ^ (fr & 7)) << 4);
+            wil_off[pl] = (wc * 32 + fr) * 128 + (((4 * pl + fq) ^ (fr & 7)) << 4);
+        }
+    }
     f32x4 acc[2][4][4];  // [mh][n][m]
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -168,8 +208,13 @@ __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (mh == 1 && i >= NF - 4) continue;
-            xf[i][0] = *(const bf16x8*)(s + x_off[i]);
-            xf[i][1] = *(const bf16x8*)(s + XPLANE + x_off[i]);
+            if constexpr (IL) {
+                xf[i][0] = *(const bf16x8*)(s + xil_off[0] + i * 2048);
+                xf[i][1] = *(const bf16x8*)(s + xil_off[1] + i * 2048);
+            } else {
+                xf[i][0] = *(const bf16x8*)(s + x_off[i]);
+                xf[i][1] = *(const bf16x8*)(s + XPLANE + x_off[i]);
+            }
         }
     };
     auto read_w = [&](bf16x8 (&w)[2][2], int tile, int nh) {
@@ -179,8 +224,13 @@ __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
         const char* s = smem + (tile & 1) * KTILE + half_off(2 * nh);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            w[j][0] = *(const bf16x8*)(s + w_off[j]);
-            w[j][1] = *(const bf16x8*)(s + WPLANE + w_off[j]);
+            if constexpr (IL) {
+                w[j][0] = *(const bf16x8*)(s + wil_off[0] + j * 2048);
+                w[j][1] = *(const bf16x8*)(s + wil_off[1] + j * 2048);
+            } else {
+                w[j][0] = *(const bf16x8*)(s + w_off[j]);
+                w[j][1] = *(const bf16x8*)(s + WPLANE + w_off[j]);
+            }
         }
     };
     auto mma = [&](auto mh_, auto nh_, bf16x8 (&w)[2][2], bool fresh_x) {
@@ -284,6 +334,17 @@ __global__ __launch_bounds__(512, 1) void conv_x3_8ph_kernel(ConvX3Args p) {
 }
 
 }  // namespace
+
+// The Linear form on interleaved split operands (ConvX3Args of a 1x1 layer over M rows; in = A_il, w = W_il; in_plane / w_plane unused)
+int ufm_launch_gemm_x3_il_8ph(const ConvX3Args& p, hipStream_t stream, int nf) {
+    const int rows = 32 * nf;
+    const dim3 grid((p.M - p.m_begin + rows - 1) / rows * (p.Cout / 256)), block(512);
+    if (nf == 5) hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4, false, 5, false, true>), grid, block, 0, stream, p);
+    else if (nf == 6) hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4, false, 6, false, true>), grid, block, 0, stream, p);
+    else if (nf == 7) hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4, false, 7, false, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((conv_x3_8ph_kernel<2, 4, false, 8, false, true>), grid, block, 0, stream, p);
+    return 0;
+}
 
 int ufm_launch_conv_x3_8ph(const ConvX3Args& p, hipStream_t stream, int nf) {
     // 256 px x 256 cout tiles (wave layout 2 x 4), 32 nf px high.  The kernel is templated on the wave layout; the 4 x 2 layout (512 px x

@@ -35,6 +35,8 @@ struct ConvX3Args {
     int splitk;
     float* slab;          // [tiles][splitk][BM * BN] partial tiles (fragment order)
     unsigned* counters;   // [tiles], zero between launches (the last arriver resets its tile's word)
+    int out_il;           // round 6: the split output is stored INTERLEAVED, [row][Cout / 32][hi 32 | lo 32] (UFM_BF16X2_IL; no residual, no out_relu, no shuffle)
+    int il;               // round 6, ufm_gemm_bf16x3_il: `in` and `w` are INTERLEAVED split operands [rows][K / 32][hi 32 | lo 32] (the 8-phase Linear form only)
     int serial_epilogue;  // A/B hook (ufm_debug_set_conv_variant bit 4): the per-pass residual read-out of rounds 1-4
     // diagnostic build only (ufm_debug_set_conv_stamps; the STAMP = true instantiation of the 8-phase kernel): 8 x uint64 per workgroup
     unsigned long long* stamps;
@@ -174,7 +176,8 @@ static __device__ __forceinline__ void conv_x3_epilogue(const ConvX3Args& p, f32
                     } else {
                         if constexpr (MODE == 1 || MODE == 2) v += unsplit(h1[i], l1[i]);
                         if constexpr (MODE == 2) v += unsplit(h2[i], l2[i]);
-                        split_store4(p.out + o, p.out_plane, v);
+                        if (MODE == 4 && p.out_il) split_store4(p.out + ((size_t)(row0 + pix0 + r) * (2 * p.Cout) + ((cb >> 5) << 6) + (cb & 31)), 32, v);
+                        else split_store4(p.out + o, p.out_plane, v);
                         if (p.out_relu) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] = relu_bits(v[j]);
@@ -227,7 +230,8 @@ static __device__ __forceinline__ void conv_x3_epilogue(const ConvX3Args& p, f32
         }
         if (p.res1) v += split_load4(p.res1 + o, p.out_plane);
         if (p.res2) v += split_load4(p.res2 + o, p.out_plane);
-        split_store4(p.out + o, p.out_plane, v);
+        if (p.out_il) split_store4(p.out + ((size_t)pix * (2 * p.Cout) + ((cb >> 5) << 6) + (cb & 31)), 32, v);
+        else split_store4(p.out + o, p.out_plane, v);
         if (p.out_relu) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = relu_bits(v[j]);
@@ -239,6 +243,7 @@ static __device__ __forceinline__ void conv_x3_epilogue(const ConvX3Args& p, f32
 // conv_bf16x3_8ph.hip: 8-phase kernels, 256 px x 256 cout (Cout % 256 == 0) or 512 px x 128 cout (Cout % 128 == 0); 32-bit operand offsets
 // conv_bf16x3_pair.hip: 256 px x 128 cout, four waves, two resident workgroups per CU (Cout % 128 == 0, at least 2 K-tiles, 32-bit operand offsets)
 int ufm_launch_conv_x3_pair(const ConvX3Args& p, hipStream_t stream);
+int ufm_launch_gemm_x3_il_8ph(const ConvX3Args& p, hipStream_t stream, int nf = 8);  // conv_bf16x3_8ph.hip: the Linear form on interleaved operands
 // conv_bf16x3_halo.hip (round 6): the 8-phase 256-cout kernel for 3x3 / stride 1 / pad 1 / zero padding with the input staged once per filter
 // row (a row-window halo tile) instead of once per tap; same tile heights (32 nf pixels), bit-identical
 int ufm_launch_conv_x3_halo(const ConvX3Args& p, hipStream_t stream, int nf = 8);

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel_fixed(const float* __res
         f32x4 y;
 #pragma unroll
         for (int j = 0; j < 4; ++j) y[j] = (v[i][j] - mean) * rstd * wv[j] + bv[j];
-        if (OUT_BF16 == 2) {
+        if (OUT_BF16 == 2 || OUT_BF16 == 3) {
             float h[4], l[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -92,9 +92,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel_fixed(const float* __res
             }
             u32x2 ph = {pack_bf16x2(h[0], h[1]), pack_bf16x2(h[2], h[3])};
             u32x2 pl = {pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3])};
-            uint16_t* o = (uint16_t*)out + (size_t)row * ldo + c * 4;
-            *(u32x2*)o = ph;
-            *(u32x2*)(o + add.out_plane) = pl;
+            if (OUT_BF16 == 3) {  // UFM_BF16X2_IL: [row][C / 32][hi 32 | lo 32] (a row is 2 ldo elements): the same values, interleaved per 32-channel chunk
+                uint16_t* o = (uint16_t*)out + (size_t)row * (2 * ldo) + ((c * 4) >> 5) * 64 + ((c * 4) & 31);
+                *(u32x2*)o = ph;
+                *(u32x2*)(o + 32) = pl;
+            } else {
+                uint16_t* o = (uint16_t*)out + (size_t)row * ldo + c * 4;
+                *(u32x2*)o = ph;
+                *(u32x2*)(o + add.out_plane) = pl;
+            }
         } else if (OUT_BF16 == 1) {
             u32x2 pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
             *(u32x2*)((uint16_t*)out + (size_t)row * ldo + c * 4) = pk;
@@ -214,7 +220,7 @@ static void launch_layernorm(const float* x, int ldx, const int32_t* row_index, 
         default: UFM_LN_FIXED(OUT, 8); break; \
     }
     if (D % 256 == 0) {
-        if (out_dtype == UFM_BF16X2) { UFM_LN_BY_VPL(2) } else if (out_dtype == UFM_BF16) { UFM_LN_BY_VPL(1) } else { UFM_LN_BY_VPL(0) }
+        if (out_dtype == UFM_BF16X2_IL) { UFM_LN_BY_VPL(3) } else if (out_dtype == UFM_BF16X2) { UFM_LN_BY_VPL(2) } else if (out_dtype == UFM_BF16) { UFM_LN_BY_VPL(1) } else { UFM_LN_BY_VPL(0) }
     } else if (out_dtype == UFM_BF16X2)
         hipLaunchKernelGGL((layernorm_kernel<2, ADD>), grid, block, 0, st, x, ldx, row_index, rows_out, D, weight, bias, eps, out, ldo, add);
     else if (out_dtype == UFM_BF16)
@@ -232,7 +238,8 @@ extern "C" int ufm_layernorm(const float* x, int ldx, const int32_t* row_index, 
     UFM_REQUIRE(rows_out > 0, "ufm_layernorm: rows_out=%d", rows_out);
     UFM_REQUIRE(D % 4 == 0 && D <= MAX_VPL * 256 && D > 0, "ufm_layernorm: D=%d must be a multiple of 4 and <= %d", D, MAX_VPL * 256);
     UFM_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && ldx >= D && ldo >= D, "ufm_layernorm: bad ldx/ldo %d/%d", ldx, ldo);
-    UFM_REQUIRE(out_dtype == UFM_F32 || out_dtype == UFM_BF16 || out_dtype == UFM_BF16X2, "ufm_layernorm: bad out_dtype");
+    UFM_REQUIRE(out_dtype == UFM_F32 || out_dtype == UFM_BF16 || out_dtype == UFM_BF16X2 || out_dtype == UFM_BF16X2_IL, "ufm_layernorm: bad out_dtype");
+    UFM_REQUIRE(out_dtype != UFM_BF16X2_IL || (D % 256 == 0 && ldo % 32 == 0), "ufm_layernorm: the interleaved split output needs D %% 256 == 0 and ldo %% 32 == 0 (D=%d, ldo=%d)", D, ldo);
     launch_layernorm<false>(x, ldx, row_index, rows_out, D, weight, bias, eps, out, out_dtype, ldo, LnAdd{nullptr, nullptr, 0, (long long)rows_out * ldo}, (hipStream_t)stream);
     UFM_CHECK_LAUNCH("ufm_layernorm");
     return UFM_OK;

@@ -55,10 +55,13 @@ def _split_bf16(w: torch.Tensor) -> torch.Tensor:
 class _Lin:
     """Packed nn.Linear: weight in the mode's operand dtype, bias fp32."""
 
-    def __init__(self, lin: nn.Linear, dev, wdt, split: bool = False):
+    def __init__(self, lin: nn.Linear, dev, wdt, split: bool = False, interleave: bool = False):
         self.n, self.k = lin.weight.shape
-        if split:  # UFM_BF16X2 (2, N, K) for ufm_gemm_bf16x3
+        self.il = False
+        if split:  # UFM_BF16X2 (2, N, K) for ufm_gemm_bf16x3 -- or, round 6, UFM_BF16X2_IL (N, K / 32, 2, 32) for ufm_gemm_bf16x3_il
             self.w = _split_bf16(lin.weight.detach().to(device=dev, dtype=torch.float32))
+            if interleave:
+                self.w, self.il = hip.interleave_split(self.w), True
         else:
             self.w = lin.weight.detach().to(device=dev, dtype=wdt).contiguous()
         self.b = _f32(lin.bias, dev) if lin.bias is not None else None
@@ -110,12 +113,21 @@ torch.nn.modules.module.register_module_module_registration_hook(_on_parameter_r
 torch.nn.modules.module.register_module_buffer_registration_hook(_on_parameter_registration)
 
 
+def _il_ok(*lins: nn.Linear) -> bool:
+    """ufm_gemm_bf16x3_il's contract for every Linear of a block: N % 256 == 0 (the 8-phase tile), K % 32 == 0, K >= 64."""
+    return all(l.weight.shape[0] % 256 == 0 and l.weight.shape[1] % 32 == 0 and l.weight.shape[1] >= 64 for l in lins)
+
+
 class _Blk:
     def __init__(self, blk, dev, wdt, split: bool = False):
         self.n1w, self.n1b = _f32(blk.norm1.weight, dev), _f32(blk.norm1.bias, dev)
         self.n2w, self.n2b = _f32(blk.norm2.weight, dev), _f32(blk.norm2.bias, dev)
-        self.qkv, self.proj = _Lin(blk.attn.qkv, dev, wdt, split), _Lin(blk.attn.proj, dev, wdt, split)
-        self.fc1, self.fc2 = _Lin(blk.mlp.fc1, dev, wdt, split), _Lin(blk.mlp.fc2, dev, wdt, split)
+        # numerics "precise" (split): the four Linears of a block on INTERLEAVED split operands where their shapes allow it (round 6:
+        # every LDS-DMA row of the bf16x3 loop a whole 128-byte line, -7...-16 % per launch; profiles/r06/gemm_x3_il_ab.log) -- LayerNorm,
+        # the attention kernel and the fc1 epilogue write that format (Engine._blocks)
+        il = self.il = bool(split) and _il_ok(blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2) and blk.norm1.weight.shape[0] % 256 == 0
+        self.qkv, self.proj = _Lin(blk.attn.qkv, dev, wdt, split, il), _Lin(blk.attn.proj, dev, wdt, split, il)
+        self.fc1, self.fc2 = _Lin(blk.mlp.fc1, dev, wdt, split, il), _Lin(blk.mlp.fc2, dev, wdt, split, il)
         self.ls1 = _f32(blk.ls1.gamma, dev) if hasattr(blk.ls1, "gamma") else None
         self.ls2 = _f32(blk.ls2.gamma, dev) if hasattr(blk.ls2, "gamma") else None
         # fast mode: the QKV epilogue scales the Q columns by softmax_scale*log2(e) BEFORE the bf16 rounding,
@@ -140,6 +152,7 @@ class _XBlk(_Blk):
     """Packed CrossBlockParams: the self-attention half is a _Blk (norm1/attn/ls1, norm3 -> n2, mlp, ls3 -> ls2)."""
 
     def __init__(self, blk, dev, wdt, split: bool = False):
+        self.il = False  # (the cross-attention variant keeps the planar split format)
         self.n1w, self.n1b = _f32(blk.norm1.weight, dev), _f32(blk.norm1.bias, dev)
         self.n2w, self.n2b = _f32(blk.norm3.weight, dev), _f32(blk.norm3.bias, dev)   # the MLP's norm
         self.qkv, self.proj = _Lin(blk.attn.qkv, dev, wdt, split), _Lin(blk.attn.proj, dev, wdt, split)
@@ -636,7 +649,10 @@ class Engine:
     def linear(self, x, lin: _Lin, M: int, out, *, act=hip.ACT_NONE, gamma=None, res=None, res_row_mod=0, out_row_group=0, lda=None):
         """out = epilogue(x @ W^T): bf16 MFMA GEMM in 'fast', the bf16x3 split form in 'precise', exact-fp32 MFMA (conv
         kernel as dense GEMM) in 'parity'."""
-        if lin.w.dim() == 3:  # UFM_BF16X2 weights: x is a (2, M, K) split buffer, out split or the fp32 residual stream
+        if lin.il:  # UFM_BF16X2_IL weights: x is an (M, K / 32, 2, 32) interleaved split buffer; out planar split (3-D), interleaved (4-D) or fp32
+            assert res_row_mod == 0 and out_row_group == 0 and lda is None and x.dim() == 4
+            hip.gemm_x3_il(x, lin.w, M, lin.n, lin.k, out, self.zero, bias=lin.b, act=act, gamma=gamma, res=res)
+        elif lin.w.dim() == 3:  # UFM_BF16X2 weights: x is a (2, M, K) split buffer, out split or the fp32 residual stream
             assert res_row_mod == 0 and out_row_group == 0 and lda is None
             hip.gemm_x3(x, lin.w, M, lin.n, lin.k, out, self.zero, bias=lin.b, act=act, gamma=gamma, res=res)
         elif lin.w.dtype == torch.bfloat16:
@@ -703,7 +719,12 @@ class Engine:
         M = Bseq * N
         x3 = self.trunk_x3
         tb = (lambda name, cols: self.buf(name + "_x2", (2, M, cols), torch.bfloat16)) if x3 else (lambda name, cols: self.buf(name, (M, cols), self.adt))
-        xn, qkv, ao, hid = tb("xn", D), tb("qkv", 3 * D), tb("ao", D), tb("hid", blocks[0].fc1.n)
+        il = x3 and all(w.il for w in blocks)  # the blocks' Linears read interleaved split operands: LayerNorm, attention and fc1 write them
+        if il:
+            ti = lambda name, cols: self.buf(name + "_il", (M, cols // 32, 2, 32), torch.bfloat16)  # noqa: E731
+            xn, qkv, ao, hid = ti("xn", D), tb("qkv", 3 * D), ti("ao", D), ti("hid", blocks[0].fc1.n)  # (qkv stays planar: the attention kernel's K / V tiles)
+        else:
+            xn, qkv, ao, hid = tb("xn", D), tb("qkv", 3 * D), tb("ao", D), tb("hid", blocks[0].fc1.n)
         defer = self.numerics == "fast" and self.defer_residual
         br = self.buf("branch", (M, D), torch.bfloat16) if defer else None
         pending = False  # x still lacks gamma * br of the previous block's fc2
@@ -713,10 +734,10 @@ class Engine:
                 hip.add_layernorm(x, D, br, pend_gamma, M, D, w.n1w, w.n1b, 1e-6, xn)
                 pending = False
             else:
-                hip.layernorm(x, D, None, M, D, w.n1w, w.n1b, 1e-6, xn, split=x3)
+                hip.layernorm(x, D, None, M, D, w.n1w, w.n1b, 1e-6, xn, split=x3, interleaved=il)
             self.linear(xn, w.qkv, M, qkv, gamma=w.qscale)
             if x3:
-                hip.attention_x3(qkv, ao, Bseq, N, heads, 0.125)
+                hip.attention_x3(qkv, ao, Bseq, N, heads, 0.125, out_interleaved=il)
             else:
                 hip.attention(qkv, ao, Bseq, N, heads, 0.0 if w.qscale is not None else 0.125)
             if defer:
@@ -724,7 +745,7 @@ class Engine:
                 hip.add_layernorm(x, D, br, w.ls1, M, D, w.n2w, w.n2b, 1e-6, xn)
             else:
                 self.linear(ao, w.proj, M, x, gamma=w.ls1, res=x)
-                hip.layernorm(x, D, None, M, D, w.n2w, w.n2b, 1e-6, xn, split=x3)
+                hip.layernorm(x, D, None, M, D, w.n2w, w.n2b, 1e-6, xn, split=x3, interleaved=il)
             self.linear(xn, w.fc1, M, hid, act=hip.ACT_GELU)
             if defer and i + 1 < len(blocks) and not needs_x(i):
                 self.linear(hid, w.fc2, M, br)

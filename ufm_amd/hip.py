@@ -16,7 +16,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libufm_hip.so")
 
-F32, BF16, BF16X2 = 0, 1, 2
+F32, BF16, BF16X2, BF16X2_IL = 0, 1, 2, 3
 ABI_VERSION = 2  # include/ufm_hip.h UFM_ABI_VERSION: bumped whenever an argument changes meaning, so a stale .so fails to load
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 
@@ -62,7 +62,9 @@ SIGNATURES = {
     "ufm_conv2d_nhwc_bf16x3": [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp],
     "ufm_conv2d_nhwc_bf16x3_grouped": [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, C.c_longlong, _vp],
     "ufm_gemm_bf16x3": [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp],
+    "ufm_gemm_bf16x3_il": [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "ufm_attention_bf16x3": [_vp, _vp, _i, _i, _i, _f, _vp],
+    "ufm_attention_bf16x3_il": [_vp, _vp, _i, _i, _i, _f, _vp],
     "ufm_upsample_bilinear_nhwc": [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp],
     "ufm_head_tail": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _ip, _fp3, _fp3, _vp, _vp, _vp],
     "ufm_adaptor_covariance2d": [_vp, _i, _i, _vp, _vp, _vp, _vp],
@@ -238,10 +240,15 @@ def gemm_bf16(A, W, M, N, K, out, *, bias=None, act=ACT_NONE, gamma=None, res=No
     )
 
 
-def layernorm(x, ldx, row_index, rows_out, D, weight, bias, eps, out, ldo=None, split=False, out_plane=None):
+def layernorm(x, ldx, row_index, rows_out, D, weight, bias, eps, out, ldo=None, split=False, out_plane=None, interleaved=False):
     """split=True: `out` is a (2, rows_out, D) bf16 tensor in the UFM_BF16X2 format.  out_plane (elements): `out` is a row
-    slice of a larger split buffer whose planes are that far apart (ufm_layernorm_slice)."""
+    slice of a larger split buffer whose planes are that far apart (ufm_layernorm_slice).  interleaved=True (with split): `out` is
+    (rows_out, D // 32, 2, 32) bf16 -- UFM_BF16X2_IL, the operand format of gemm_x3_il."""
     _t("ufm_layernorm", rows_out * D * (4.0 + (4 if split else out.element_size())))
+    if interleaved:
+        assert split and out_plane is None and out.dtype == torch.bfloat16
+        _check(lib().ufm_layernorm(_p(x), ldx, _p(row_index), rows_out, D, _p(weight), _p(bias), eps, _p(out), BF16X2_IL, ldo or D, _stream()), "ufm_layernorm")
+        return
     if out_plane is not None:
         _check(lib().ufm_layernorm_slice(_p(x), ldx, _p(row_index), rows_out, D, _p(weight), _p(bias), eps, _p(out), BF16X2 if split else _dt(out), ldo or D, int(out_plane), _stream()), "ufm_layernorm_slice")
         return
@@ -287,9 +294,29 @@ def gemm_x3(A, W, M, N, K, out, zero_page, *, bias=None, act=ACT_NONE, gamma=Non
     _check(lib().ufm_gemm_bf16x3(_p(A), _p(W), M, N, K, _p(bias), act, _p(gamma), _p(res), _p(out), BF16X2 if split_out else F32, _p(zero_page), _stream()), "ufm_gemm_bf16x3")
 
 
-def attention_x3(qkv, out, B, N, H, scale):
-    """Attention on the split format: qkv (2, B*N, 3*H*64), out (2, B*N, H*64) bf16 planes."""
+def gemm_x3_il(A, W, M, N, K, out, zero_page, *, bias=None, act=ACT_NONE, gamma=None, res=None):
+    """gemm_x3 on INTERLEAVED split operands: A (M, K // 32, 2, 32), W (N, K // 32, 2, 32) bf16 (interleave_split()); outputs as gemm_x3, or -- a
+    4-D bf16 `out` (M, N // 32, 2, 32) -- interleaved too."""
+    split_out = out.dtype == torch.bfloat16
+    out_il = split_out and out.dim() == 4
+    assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and (split_out or out.dtype == torch.float32)
+    _t("ufm_gemm_bf16x3", (2.0 * M * N * K, f"M{M} N{N} K{K} " + ("split out" + (" GELU" if act == ACT_GELU else "") if split_out else "f32 += (read-modify-write)" if res is not None else "f32 out") + " [il]"))
+    _check(lib().ufm_gemm_bf16x3_il(_p(A), _p(W), M, N, K, _p(bias), act, _p(gamma), _p(res), _p(out), (BF16X2_IL if out_il else BF16X2) if split_out else F32, _p(zero_page), _stream()), "ufm_gemm_bf16x3_il")
+
+
+def interleave_split(planes: torch.Tensor) -> torch.Tensor:
+    """(2, rows, C) split planes -> (rows, C // 32, 2, 32): the UFM_BF16X2_IL layout (a pack-time / test-time re-layout, plain torch)."""
+    two, rows, C = planes.shape
+    assert two == 2 and C % 32 == 0
+    return planes.view(2, rows, C // 32, 32).permute(1, 2, 0, 3).contiguous()
+
+
+def attention_x3(qkv, out, B, N, H, scale, out_interleaved=False):
+    """Attention on the split format: qkv (2, B*N, 3*H*64), out (2, B*N, H*64) bf16 planes -- or, out_interleaved, (B*N, H*2, 2, 32): UFM_BF16X2_IL."""
     _t("ufm_attention_bf16x3", 4.0 * B * H * N * N * 64)
+    if out_interleaved:
+        _check(lib().ufm_attention_bf16x3_il(_p(qkv), _p(out), B, N, H, scale, _stream()), "ufm_attention_bf16x3_il")
+        return
     _check(lib().ufm_attention_bf16x3(_p(qkv), _p(out), B, N, H, scale, _stream()), "ufm_attention_bf16x3")
 
 
