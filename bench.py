@@ -27,6 +27,8 @@ Rank 0 prints ONE JSON line.  Extra objects:
                 HIP-graph replay (ufm_amd.GraphedPredictor).
   config4 / config5   BASELINE.json's other single-GPU configurations under the same clock (side legs, rank 0, N=1): UFM-Refine
                 518^2 batch 8 and UFM-Base 1036^2 batch 2 -- pairs/s, ms/step, per-family MFMA fractions (attention at N = 10 954).
+  pipeline_kernels   the per-family table of the dispatch the headline runs: instrumented TWO-stream steps (events per launch on each micro-batch /
+                head stream); `roofline` stays the single-stream leg (kernels do not overlap there) and says which tile policy each was measured under.
   default_res   the reference's class-default resolution (inference_resolution=None -> 560 x 420, base.py:89-90) at B = 8 on 1080 x 810 inputs (side leg).
   roofline.clock_ghz / frac_at_clock   the clock the chip holds under the dominant family (s_memtime / s_memrealtime stamps of the
                 diagnostic GEMM instantiations after 2 s of load) and `achieved` against the peak AT that clock.
@@ -75,9 +77,10 @@ class _Ms:
 
 
 def instrumented_steps(run, reps: int = 3):
-    """`reps` single-stream instrumented steps (HIP events around every C-ABI launch, on the launch stream); per launch -- the steps issue the
-    same launches in the same order -- the MEDIAN duration over the steps.  One step alone carries first-touch outliers (the single-stream
-    workspace is first used here: one QKV launch of 24 at 600 us moved that shape's average from 133 to 160 us in a round-5 run).
+    """`reps` instrumented steps (HIP events around every C-ABI launch, on the launch stream of the launching thread); per launch -- the steps
+    issue the same launches in the same order ON EACH STREAM -- the MEDIAN duration over the steps.  One step alone carries first-touch outliers (the
+    single-stream workspace is first used here: one QKV launch of 24 at 600 us moved that shape's average from 133 to 160 us in a round-5 run).
+    Works for the engine's two-stream steps too: launches are keyed by (stream, position on that stream).
     Returns (summary, records) in hip.KernelTimer's formats."""
     from ufm_amd import hip as _hip
     import torch as _torch
@@ -88,10 +91,13 @@ def instrumented_steps(run, reps: int = 3):
         try:
             run()
             _torch.cuda.synchronize()
-            recs = _hip.TIMER.records
+            recs, strs = list(_hip.TIMER.records), list(_hip.TIMER.streams)
         finally:
             _hip.TIMER = None
-        per_step.append([(name, e0.elapsed_time(e1), meta) for name, e0, e1, meta in recs])
+        by_stream = {}
+        for (name, e0, e1, meta), st in zip(recs, strs):
+            by_stream.setdefault(st, []).append((name, e0.elapsed_time(e1), meta))
+        per_step.append([r for st in sorted(by_stream) for r in by_stream[st]])
     base = per_step[-1]
     same = [st for st in per_step if len(st) == len(base) and all(a[0] == b[0] for a, b in zip(st, base))]
     records, summ = [], {}
@@ -104,6 +110,28 @@ def instrumented_steps(run, reps: int = 3):
         d["launches"] += 1
         d["metas"].append(meta)
     return summ, records
+
+
+def pipeline_families(model, src, tgt, wall_ms: float) -> dict:
+    """the per-family table of the dispatch the HEADLINE runs -- three instrumented TWO-stream steps (the timed configuration:
+    micro-batch streams flagged with ufm_hint_concurrent_stream, CU-time tile policy, the heads on their own streams), HIP events around every
+    launch on its own stream, per-launch medians.  Launches of different streams overlap in time, so a family's summed launch time is NOT its
+    share of the step: `frac` here = algorithmic work / summed launch durations / peak is the rate a launch sustains WHILE SHARING the chip with
+    the other stream's kernels, and `sum_ms / wall` says how much of it overlapped."""
+    summ, records = instrumented_steps(lambda: model.predict_correspondences_batched(src, tgt))
+    fam, total = {}, 0.0
+    for name, d in summ.items():
+        total += d["ms"]
+        e = {"launches": d["launches"], "sum_ms": round(d["ms"], 3)}
+        if name in MFMA_PEAKS:
+            work = sum(meta_work(m) for m in d["metas"])
+            e["frac_while_sharing"] = round(work / (d["ms"] * 1e-3) / 1e12 / MFMA_PEAKS[name], 4)
+            if name == "ufm_gemm_bf16":
+                e["per_shape_frac"] = {t.replace(" (read-modify-write)", "").replace(" out", ""): r["frac"] for t, r in per_shape_table([r for r in records if r[0] == name], MFMA_PEAKS[name]).items() if r["launches"] > 1}
+        fam[name.replace("ufm_", "")] = e
+    return {"families": fam, "sum_of_launch_ms": round(total, 3), "wall_ms_per_step": round(wall_ms, 3), "overlap_factor": round(total / wall_ms, 3),
+            "dispatch": "two micro-batch streams flagged concurrent (CU-time tile policy), heads on two streams: the timed configuration",
+            "how": "three instrumented two-stream steps, HIP events around every launch on its own stream, per-launch medians keyed by (stream, position)"}
 
 
 def per_shape_table(d, peak_tflops: float):
@@ -157,10 +185,12 @@ def order_line(line: dict, pairs_per_step: int) -> dict:
         if ps:
             summary["gemm_shape_frac"] = {t.replace(" (read-modify-write)", "").replace(" out", ""): r["frac"] for t, r in ps.items() if r["launches"] > 1}
     for k, v in line.items():
-        if k not in out and k not in ("kernels", "precise_mode", "roofline", "attention", "check_vs_oracle", "latency_b1_ms", "parity_mode", "end_to_end", "attention_share", "config4", "config5", "default_res"):
+        if k not in out and k not in ("kernels", "precise_mode", "roofline", "attention", "check_vs_oracle", "latency_b1_ms", "parity_mode", "end_to_end", "attention_share", "config4", "config5", "default_res", "pipeline_kernels"):
             out[k] = v
     if pm is not None:
         out["precise_mode"] = pm
+    if "pipeline_kernels" in line:
+        out["pipeline_kernels"] = line["pipeline_kernels"]
     for k in ("config4", "config5", "default_res", "parity_mode", "check_vs_oracle", "latency_b1_ms", "attention", "end_to_end", "attention_share", "roofline"):
         if k in line:
             out[k] = line[k]
@@ -189,6 +219,10 @@ def order_line(line: dict, pairs_per_step: int) -> dict:
         cv = (kernels or {}).get("ufm_conv2d_nhwc_bf16x3", {})
         if "clock_ghz" in cv:
             summary["conv_clock_ghz"], summary["conv_frac_at_clock"] = round(cv["clock_ghz"], 3), round(cv["frac_at_clock"], 4)
+    if "pipeline_kernels" in line:
+        pk = line["pipeline_kernels"]
+        summary["pipeline_frac_while_sharing"] = {k: v["frac_while_sharing"] for k, v in pk["families"].items() if "frac_while_sharing" in v}
+        summary["pipeline_overlap_factor"] = pk["overlap_factor"]
     for k in ("config4", "config5", "default_res"):
         if k in line:
             c = line[k]
@@ -651,6 +685,9 @@ def main():
             line["attention"] = {"achieved": a["achieved"], "peak": a["peak"], "unit": "TFLOP/s", "frac": a["frac"], "ms_per_step": a["ms_per_step"]}
         line["kernels"] = kernels
         line["instrumented_step_ms"] = sum(v["ms_per_step"] for v in kernels.values())
+        if args.micro_batches > 1 and B >= 4:
+            line["pipeline_kernels"] = pipeline_families(model, src, tgt, line["ms_per_step"])
+            line["roofline"]["dispatch_policy"] = "latency (single-stream instrumented leg); the timed two-stream steps run the CU-time policy: see pipeline_kernels"
 
     # ---- CPU baseline: the oracle on this box's host cores, bounded sample ----
     ref_oracle = None

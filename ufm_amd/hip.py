@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import Optional, Sequence
 
 import torch
@@ -113,11 +114,22 @@ def lib() -> C.CDLL:
 
 class KernelTimer:
     """Optional HIP-event bracket around every C-ABI launch (bench.py's per-kernel durations).
-    Events are recorded on the stream the kernels are launched on (torch's current stream)."""
+    Events are recorded on the stream the kernels are launched on (torch's current stream OF THE CALLING THREAD: the engine's two
+    micro-batch workers each bracket their own launches on their own stream; `streams[i]` is the raw handle records[i] ran on)."""
 
     def __init__(self):
         self.records = []  # (name, start_event, end_event, meta)
-        self._open = None
+        self.streams = []  # raw stream handle of each record
+        self._tl = threading.local()
+        self._lock = threading.Lock()
+
+    @property
+    def _open(self):
+        return getattr(self._tl, "open", None)
+
+    @_open.setter
+    def _open(self, v):
+        self._tl.open = v
 
     def begin(self, name: str, meta=None):
         e0 = torch.cuda.Event(enable_timing=True)
@@ -128,7 +140,9 @@ class KernelTimer:
         name, e0, meta = self._open
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        self.records.append((name, e0, e1, meta))
+        with self._lock:
+            self.records.append((name, e0, e1, meta))
+            self.streams.append(_stream())
 
     def summary(self):
         torch.cuda.synchronize()
@@ -150,8 +164,9 @@ if _raw_stream is None or _cur_device is None:  # an older / newer torch without
     _cur_device = torch.cuda.current_device
 
 
-def _check(rc: int, name: str) -> None:
-    if TIMER is not None and TIMER._open is not None and TIMER._open[0] == name:
+def _check(rc: int, name: str, family: Optional[str] = None) -> None:
+    """`family`: the KernelTimer name this entry point is booked under when it differs from the entry point's own (the _il forms)."""
+    if TIMER is not None and TIMER._open is not None and TIMER._open[0] == (family or name):
         TIMER.end()
         TIMER._open = None
     if rc != 0:
@@ -301,7 +316,7 @@ def gemm_x3_il(A, W, M, N, K, out, zero_page, *, bias=None, act=ACT_NONE, gamma=
     out_il = split_out and out.dim() == 4
     assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and (split_out or out.dtype == torch.float32)
     _t("ufm_gemm_bf16x3", (2.0 * M * N * K, f"M{M} N{N} K{K} " + ("split out" + (" GELU" if act == ACT_GELU else "") if split_out else "f32 += (read-modify-write)" if res is not None else "f32 out") + " [il]"))
-    _check(lib().ufm_gemm_bf16x3_il(_p(A), _p(W), M, N, K, _p(bias), act, _p(gamma), _p(res), _p(out), (BF16X2_IL if out_il else BF16X2) if split_out else F32, _p(zero_page), _stream()), "ufm_gemm_bf16x3_il")
+    _check(lib().ufm_gemm_bf16x3_il(_p(A), _p(W), M, N, K, _p(bias), act, _p(gamma), _p(res), _p(out), (BF16X2_IL if out_il else BF16X2) if split_out else F32, _p(zero_page), _stream()), "ufm_gemm_bf16x3_il", "ufm_gemm_bf16x3")
 
 
 def interleave_split(planes: torch.Tensor) -> torch.Tensor:
@@ -315,7 +330,7 @@ def attention_x3(qkv, out, B, N, H, scale, out_interleaved=False):
     """Attention on the split format: qkv (2, B*N, 3*H*64), out (2, B*N, H*64) bf16 planes -- or, out_interleaved, (B*N, H*2, 2, 32): UFM_BF16X2_IL."""
     _t("ufm_attention_bf16x3", 4.0 * B * H * N * N * 64)
     if out_interleaved:
-        _check(lib().ufm_attention_bf16x3_il(_p(qkv), _p(out), B, N, H, scale, _stream()), "ufm_attention_bf16x3_il")
+        _check(lib().ufm_attention_bf16x3_il(_p(qkv), _p(out), B, N, H, scale, _stream()), "ufm_attention_bf16x3_il", "ufm_attention_bf16x3")
         return
     _check(lib().ufm_attention_bf16x3(_p(qkv), _p(out), B, N, H, scale, _stream()), "ufm_attention_bf16x3")
 
