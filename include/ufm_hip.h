@@ -178,7 +178,10 @@ int ufm_debug_set_gemm_stamps(unsigned long long* buf, int rows);
 int ufm_debug_set_conv_stamps(unsigned long long* buf, int rows);
 /* Tuning hook, bit mask: bit 0 -- ufm_attention_bf16 (scale == 0 form) with 2 waves per workgroup instead of 4 (default);
  * bit 1 -- ufm_attention_bf16x3 / ufm_cross_attention_bf16x3 on the round-1 kernel (attention_bf16x3.hip) instead of round 5's
- * LDS-DMA kernel (attention_bf16x3_pw.hip); the two agree bit for bit. */
+ * LDS-DMA kernel (attention_bf16x3_pw.hip); bit 2 -- that kernel with 8 waves per workgroup (A/B); bit 3 -- that kernel with the per-tile
+ * running maximum of rounds 1-5 (bitwise the round-1 kernel) instead of round 6's FIXED softmax reference (the row's maximum over its first key
+ * tile, -m_ref as the C operand of the first QK^T MFMA, a cold 2^-64 shift if a row sum passes 2^64: the same softmax with other roundings,
+ * tested against fp64; -1.2 of 7.1 VALU instructions per MFMA in an issue-bound kernel). */
 int ufm_debug_set_attn_variant(int v);
 /* Tuning hook for ufm_conv2d_nhwc_bf16x3: 0 = auto, 1 = 128-row kernels only, 2 = 256x256 8-phase kernel wherever applicable,
  * 4 = the 256 px x 128 cout two-resident-workgroups kernel of round 5 (conv_bf16x3_pair.hip) wherever applicable,

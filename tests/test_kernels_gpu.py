@@ -1276,14 +1276,48 @@ def test_attention_bf16x3_round5_kernel_is_bitwise_the_round1_kernel(hip, B, N, 
         lib.ufm_debug_set_attn_variant(2)  # the round-1 kernel
         want = torch.full((2, B * N, H * 64), 7.0, device=DEV, dtype=torch.bfloat16)
         hip.attention_x3(qs, want, B, N, H, 0.125)
-        for variant in (0, 4):  # four waves per workgroup (shipped), eight (A/B)
+        for variant in (8, 12):  # the running-maximum form (bit 3; round 6's default is the fixed softmax reference): four waves per workgroup, eight (A/B)
             lib.ufm_debug_set_attn_variant(variant)
             for rep in range(4):
                 got = torch.full((2, B * N, H * 64), 3.0, device=DEV, dtype=torch.bfloat16)
                 hip.attention_x3(qs, got, B, N, H, 0.125)
                 assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (variant, rep)
+        # round 6's default (fixed reference): the same softmax with other roundings -- close to the round-1 kernel, and repeatable bit for bit
+        lib.ufm_debug_set_attn_variant(0)
+        a = torch.full((2, B * N, H * 64), 3.0, device=DEV, dtype=torch.bfloat16)
+        hip.attention_x3(qs, a, B, N, H, 0.125)
+        ref = attn_ref(unsplit(qs.cpu()), B, N, H, 0.125)
+        e_new, e_old = (unsplit(a.cpu()).double() - ref).abs().max().item(), (unsplit(want.cpu()).double() - ref).abs().max().item()
+        assert e_new <= max(1e-4, 1.05 * e_old + 1e-6), (e_new, e_old)  # (the test's x 9 key is 2^233 above its row's first tile: the cold re-reference path; measured 1.22e-4 for BOTH kernels on it)
+        for rep in range(3):
+            b_ = torch.full((2, B * N, H * 64), 5.0, device=DEV, dtype=torch.bfloat16)
+            hip.attention_x3(qs, b_, B, N, H, 0.125)
+            assert torch.equal(a.view(torch.int16), b_.view(torch.int16)), rep
     finally:
         lib.ufm_debug_set_attn_variant(0)
+
+
+@pytest.mark.parametrize("first_tile_high", [False, True])
+def test_attention_bf16x3_fixed_reference_shift_path(hip, first_tile_high):
+    """Round 6: the split-precision kernel's softmax reference is the row's maximum over its FIRST key tile.  (a) Later keys scoring far above it
+    (here up to 2^150 times the first tile's weight): the cold path moves the reference up to that tile's maximum and redoes the tile, repeatedly; (b) a first tile far ABOVE everything
+    else: later weights underflow towards zero, as they should.  Both against the fp64 softmax, every row (SDPA under
+    /root/reference/uniflowmatch/models/base.py:272-274)."""
+    B, N, H = 1, 64 * 7 + 5, 2
+    qkv = rnd(B * N, 3 * H * 64, seed=21, scale=0.5)
+    if first_tile_high:
+        qkv[5, H * 64 : H * 64 + 64] = qkv[9, 0:64] * 40.0          # key 5 (tile 0) aligned with query 9: ~ +80 in the exponent, nothing later comes close
+    else:
+        for t in range(1, 6):
+            qkv[t * 64 + 13, H * 64 : H * 64 + 64] = qkv[3, 0:64] * (12.0 * t)  # query 3: scores growing by ~24 nats per tile (2^35 per step)
+    qs = split(qkv)
+    ref = attn_ref(unsplit(qs), B, N, H, 0.125)
+    out = torch.zeros(2, B * N, H * 64, device=DEV, dtype=torch.bfloat16)
+    hip.attention_x3(qs.to(DEV), out, B, N, H, 0.125)
+    got = unsplit(out.cpu()).double()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item()
+    assert err <= 1e-4, err
 
 
 def test_attention_bf16x3_spike_moves_the_running_maximum(hip):

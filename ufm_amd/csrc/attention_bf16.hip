@@ -225,13 +225,16 @@ int ufm_launch_attn_pw2(const uint16_t* q, int ldq, int q_bs, const uint16_t* k,
 static int g_attn_debug = 0;   // bit 0 of the variant: the bf16 LDS-DMA kernel with 2 waves per workgroup
 static int g_attn_x3_old = 0;  // bit 1: ufm_attention_bf16x3 / ufm_cross_attention_bf16x3 on the round-1 kernel (A/B, bitwise reference)
 static int g_attn_x3_waves = 4;  // bit 2: the round-5 split-precision kernel with 8 waves per workgroup (A/B)
+static int g_attn_x3_fixref = 1; // bit 3 SET: the split-precision LDS-DMA kernel with the per-tile running maximum (bitwise the round-1 kernel) instead of round 6's fixed softmax reference
 int ufm_attn_x3_use_old() { return g_attn_x3_old; }
 int ufm_attn_x3_waves() { return g_attn_x3_waves; }
+int ufm_attn_x3_fixref() { return g_attn_x3_fixref && g_attn_x3_waves == 4; }
 extern "C" int ufm_debug_set_attn_variant(int v) {  // bit 0: 0 = 4 waves per workgroup (default), 1 = 2 waves; bit 1: the round-1 split-precision kernel
-    if (v < 0 || v > 7) {
-        ufm_set_error("ufm_debug_set_attn_variant: %d is not in 0..7 (bit 0: 2-wave bf16 kernel, bit 1: round-1 bf16x3 kernel, bit 2: 8-wave bf16x3 kernel)", v);
+    if (v < 0 || v > 15) {
+        ufm_set_error("ufm_debug_set_attn_variant: %d is not in 0..15 (bit 0: 2-wave bf16 kernel, bit 1: round-1 bf16x3 kernel, bit 2: 8-wave bf16x3 kernel, bit 3: bf16x3 LDS-DMA kernel with the running maximum)", v);
         return UFM_ERR_ARG;
     }
+    g_attn_x3_fixref = (v & 8) ? 0 : 1;
     g_attn_debug = v & 1;
     g_attn_x3_old = (v >> 1) & 1;
     g_attn_x3_waves = (v & 4) ? 8 : 4;

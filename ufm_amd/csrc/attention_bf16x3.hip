@@ -245,9 +245,10 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(const uint16_t* __restr
 
 // attention_bf16x3_pw.hip: the round-5 kernel (one wave per SIMD, two q-blocks per wave, LDS-DMA rings); bitwise this file's kernel
 int ufm_launch_attn_x3_pw(const uint16_t* q, int ldq, long long q_plane, const uint16_t* k, const uint16_t* v, int ldkv, long long in_plane,
-                          uint16_t* out, int ldo, long long out_plane, int B, int Nq, int Nk, int H, float c, hipStream_t stream, int waves, int out_il = 0);
+                          uint16_t* out, int ldo, long long out_plane, int B, int Nq, int Nk, int H, float c, hipStream_t stream, int waves, int out_il = 0, int fixref = 0);
 int ufm_attn_x3_use_old();  // attention_bf16.hip: ufm_debug_set_attn_variant bit 1
-int ufm_attn_x3_waves();    // bit 2: eight waves per workgroup instead of four
+int ufm_attn_x3_waves();
+int ufm_attn_x3_fixref();  // attention_bf16.hip: ufm_debug_set_attn_variant bit 3 clear    // bit 2: eight waves per workgroup instead of four
 
 extern "C" int ufm_attention_bf16x3(const uint16_t* qkv, uint16_t* out, int B, int N, int H, float scale, void* stream) {
     UFM_REQUIRE(qkv && out, "ufm_attention_bf16x3: null pointer");
@@ -260,7 +261,7 @@ extern "C" int ufm_attention_bf16x3(const uint16_t* qkv, uint16_t* out, int B, i
     const bool pw_ok = !ufm_attn_x3_use_old() && (long long)N * 3 * H * 64 * 2 < (1ll << 31);
     if (pw_ok)
         ufm_launch_attn_x3_pw(qkv, 3 * H * 64, rows * 3 * H * 64, qkv + H * 64, qkv + 2 * H * 64, 3 * H * 64, rows * 3 * H * 64, out, H * 64, rows * H * 64, B, N, N, H,
-                              scale * 1.44269504088896340736f, (hipStream_t)stream, ufm_attn_x3_waves());
+                              scale * 1.44269504088896340736f, (hipStream_t)stream, ufm_attn_x3_waves(), 0, ufm_attn_x3_fixref());
     else
     hipLaunchKernelGGL(attn_x3_kernel, grid, block, 0, (hipStream_t)stream, qkv, 3 * H * 64, rows * 3 * H * 64, qkv + H * 64, qkv + 2 * H * 64, 3 * H * 64,
                        rows * 3 * H * 64, out, H * 64, rows * H * 64, N, N, H, scale * 1.44269504088896340736f);
@@ -278,7 +279,7 @@ extern "C" int ufm_attention_bf16x3_il(const uint16_t* qkv, uint16_t* out, int B
     UFM_REQUIRE(!ufm_attn_x3_use_old() && (long long)N * 3 * H * 64 * 2 < (1ll << 31), "ufm_attention_bf16x3_il: the interleaved output exists in the LDS-DMA kernel only (variant bit 1 clear, N * 3 H * 128 B < 2 GiB)");
     const long long rows = (long long)B * N;
     ufm_launch_attn_x3_pw(qkv, 3 * H * 64, rows * 3 * H * 64, qkv + H * 64, qkv + 2 * H * 64, 3 * H * 64, rows * 3 * H * 64, out, H * 64, rows * H * 64, B, N, N, H,
-                          scale * 1.44269504088896340736f, (hipStream_t)stream, ufm_attn_x3_waves(), 1);
+                          scale * 1.44269504088896340736f, (hipStream_t)stream, ufm_attn_x3_waves(), 1, ufm_attn_x3_fixref());
     UFM_CHECK_LAUNCH("ufm_attention_bf16x3_il");
     return UFM_OK;
 }
@@ -292,7 +293,7 @@ extern "C" int ufm_cross_attention_bf16x3(const uint16_t* q, int ldq, const uint
     dim3 grid(((Nq + QB - 1) / QB) * H * B), block(256);
     if (!ufm_attn_x3_use_old() && (long long)Nk * ldkv * 2 < (1ll << 31))
         ufm_launch_attn_x3_pw(q, ldq, (long long)B * Nq * ldq, k, v, ldkv, (long long)B * Nk * ldkv, out, ldo, (long long)B * Nq * ldo, B, Nq, Nk, H,
-                              scale * 1.44269504088896340736f, (hipStream_t)stream, ufm_attn_x3_waves());
+                              scale * 1.44269504088896340736f, (hipStream_t)stream, ufm_attn_x3_waves(), 0, ufm_attn_x3_fixref());
     else
     hipLaunchKernelGGL(attn_x3_kernel, grid, block, 0, (hipStream_t)stream, q, ldq, (long long)B * Nq * ldq, k, v, ldkv, (long long)B * Nk * ldkv, out, ldo,
                        (long long)B * Nq * ldo, Nq, Nk, H, scale * 1.44269504088896340736f);

@@ -48,7 +48,13 @@ __device__ __forceinline__ void glds16(const char* gbase, unsigned voff, unsigne
 }
 __device__ __forceinline__ unsigned lds_addr_of(const char* p) { return (unsigned)(uintptr_t)LDS_PTR(p); }
 
-template <int NW>
+// FIXREF (round 6): the softmax reference of a query row is FIXED after the first key tile (its maximum there) instead of following the running
+// maximum: -m_ref rides in as the C operand of every tile's first QK^T MFMA, P = exp2(c (S - m_ref)) needs no per-tile maximum (32 fmax, the
+// cross-half exchange, alpha) and O no per-tile rescale; only if a tile's weights pass 2^54 (keys scoring far above the first tile's) the reference is moved up
+// to that tile's maximum in a cold, wave-uniform path in front of P.V (any jump is handled: the tile's softmax is redone).  The bf16 kernel's scheme (attention_bf16_pw.hip); PMC put this kernel at 7.1 VALU instructions per MFMA,
+// issue-bound -- this takes 1.2 of them out.  The same softmax in exact arithmetic, other roundings: NOT bitwise the round-1 kernel
+// (FIXREF = false stays that, ufm_debug_set_attn_variant bit 1 or the ufm_attention_bf16x3 test hook selects it); tested against fp64.
+template <int NW, bool FIXREF = false>
 __global__ __launch_bounds__(NW * 64, 8 / NW) void attn_x3_pw_kernel(const uint16_t* __restrict__ qp_, int ldq, long long q_plane,
                                                             const uint16_t* __restrict__ kp_, const uint16_t* __restrict__ vp_, int ldkv, long long in_plane,
                                                             uint16_t* __restrict__ out, int ldo, long long out_plane, int Nq, int N, int H, float c, int out_il) {
@@ -162,9 +168,33 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attn_x3_pw_kernel(const uint1
     // exchange, alpha and the exponent offset),  pieces 8..23 = one pair of scores each: exp2, row sum, (hi, lo) split.
     float mloc = 0.f, mc = 0.f, lsum = 0.f;
     unsigned pkh[8], pkl[8];
+    f32x16 negm;  // FIXREF: -m_ref in every element (the C operand of a tile's first QK^T MFMA)
+    float l_prev = 0.f;  // FIXREF: the row sum in front of the current tile (the cold re-reference path restarts from it)
     auto softmax_piece = [&](f32x16 (&st)[2], auto j_) {
         constexpr int J = decltype(j_)::value;
-        if constexpr (J < 8) {
+        if constexpr (FIXREF) {  // 16 score pairs over the 24 gaps (pair P in gap 3 P / 2): scale, exp2, row sum, (hi, lo) split
+            if constexpr (J % 3 != 2) {
+                constexpr int P = (J / 3) * 2 + (J % 3), kt = P >> 3, r = 2 * (P & 7);
+                if constexpr (P == 0) lsum = 0.f;
+                const float p0 = __builtin_amdgcn_exp2f(st[kt][r] * c);
+                const float p1 = __builtin_amdgcn_exp2f(st[kt][r + 1] * c);
+                lsum += p0 + p1;
+                const unsigned h = pack_bf16x2(p0, p1);
+                pkh[r >> 1] = h;
+                pkl[r >> 1] = pack_bf16x2(p0 - __uint_as_float(h << 16), p1 - __uint_as_float(h & 0xffff0000u));
+                if constexpr ((P & 7) == 7) {
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        u32x4 wh = {pkh[4 * s2], pkh[4 * s2 + 1], pkh[4 * s2 + 2], pkh[4 * s2 + 3]};
+                        u32x4 wl = {pkl[4 * s2], pkl[4 * s2 + 1], pkl[4 * s2 + 2], pkl[4 * s2 + 3]};
+                        ph[kt][s2] = __builtin_bit_cast(bf16x8, wh);
+                        pl[kt][s2] = __builtin_bit_cast(bf16x8, wl);
+                    }
+                }
+                if constexpr (P == 15) l_prev = l_run, l_run += lsum;
+                asm volatile("" : "+v"(pkh[r >> 1]), "+v"(pkl[r >> 1]), "+v"(lsum));
+            }
+        } else if constexpr (J < 8) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int idx = 4 * J + i;
@@ -201,7 +231,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attn_x3_pw_kernel(const uint1
             // produced HERE: without a pin LLVM sinks the whole piece to its first use (slot Y), out of the MFMA gap it is meant to fill
             asm volatile("" : "+v"(pkh[r >> 1]), "+v"(pkl[r >> 1]), "+v"(lsum));
         }
-        if constexpr (J < 8) asm volatile("" : "+v"(mloc));
+        if constexpr (!FIXREF && J < 8) asm volatile("" : "+v"(mloc));
     };
     // slot X: S(t + 1) = K(t + 1) . Q^T (eight fragment pairs x three MFMAs, the next pair's LDS reads issued a pair ahead) with one
     // piece of softmax(S(t)) behind every MFMA; sched_barrier pins each piece into its gap (left alone, hipcc ran the MFMAs in two
@@ -213,7 +243,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attn_x3_pw_kernel(const uint1
         auto group = [&](auto g_) {
             constexpr int G = decltype(g_)::value, kt = G >> 2, s_ = G & 3, b_ = G & 1;
             if constexpr (G + 1 < 8) k_frag(fh[b_ ^ 1], fl[b_ ^ 1], ks, (G + 1) >> 2, (G + 1) & 3);
-            nxt[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[b_], qh[s_], s_ == 0 ? zero : nxt[kt], 0, 0, 0);
+            nxt[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[b_], qh[s_], s_ == 0 ? (FIXREF ? negm : zero) : nxt[kt], 0, 0, 0);
             softmax_piece(cur, IC<3 * G>{});
             __builtin_amdgcn_sched_barrier(0);
             nxt[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b_], qlo[s_], nxt[kt], 0, 0, 0);
@@ -277,11 +307,40 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attn_x3_pw_kernel(const uint1
             softmax_alone(cur);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (__any(moved)) {  // wave-uniform: after the first tiles the running maxima rarely move (alpha == 1 exactly otherwise)
+        if constexpr (FIXREF) {
+            // cold path (wave-uniform): this tile holds keys scoring far above the row's reference -- a weight beyond 2^54, or already inf / NaN.
+            // Nothing of the tile has reached O yet and S'(t) is still in `cur`: move the reference up to the tile's own maximum (rows that stay
+            // below theirs keep it), scale O and the row sum down accordingly (they may underflow to 0: then they ARE negligible), correct the
+            // scores slot X has already built for tile t + 1, and redo this tile's softmax.  Any jump is handled, at the price of one compare
+            // and one ballot per tile in the hot path.
+            if (__any(!(lsum <= 1.152921504606847e18f))) {
+                float tm = cur[0][0];
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+                for (int idx = 1; idx < 32; ++idx) tm = fmaxf(tm, cur[idx >> 4][idx & 15]);
+                tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+                const float dm = fmaxf(tm, 0.0f);
+                const float f = __builtin_amdgcn_exp2f(-dm * c);
+                l_run = l_prev * f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[dt][r] *= f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) negm[r] -= dm;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cur[kt][r] -= dm, nxt[kt][r] -= dm;
+                softmax_alone(cur);
+            }
+        }
+        if constexpr (!FIXREF) {
+            if (__any(moved)) {  // wave-uniform: after the first tiles the running maxima rarely move (alpha == 1 exactly otherwise)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         slot_y(smem + V_RING + (t & 1) * STG);
@@ -297,6 +356,19 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attn_x3_pw_kernel(const uint1
     __builtin_amdgcn_sched_barrier(0);
     if (nt > 1) stage(IC<0>{}, 1);
     qk_plain(sa, smem);
+    if constexpr (FIXREF) {  // the reference: this row's maximum over the first key tile (both halves of the column), then S(0) -= m_ref
+        if (nt == 1 && KB > N) mask_tail(sa, 0);
+        float m0 = sa[0][0];
+#pragma unroll
+        for (int idx = 1; idx < 32; ++idx) m0 = fmaxf(m0, sa[idx >> 4][idx & 15]);
+        m0 = fmaxf(m0, __shfl_xor(m0, 32, 64));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[r] = -m0;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sa[kt][r] -= m0;
+    }
     __builtin_amdgcn_sched_barrier(0);
     // (the iteration's top barrier also orders the K(1) DMA above behind every wave's K(0) reads: K(2) is the first to reuse stage 0)
     int t = 0;
@@ -337,10 +409,11 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attn_x3_pw_kernel(const uint1
 // q / k / v: first element of head 0 of batch item 0 (hi plane); the lo planes follow q_plane / in_plane / out_plane elements behind.
 // The host has checked shapes, alignment and that one batch item's K / V rows fit a 32-bit byte offset.
 int ufm_launch_attn_x3_pw(const uint16_t* q, int ldq, long long q_plane, const uint16_t* k, const uint16_t* v, int ldkv, long long in_plane,
-                          uint16_t* out, int ldo, long long out_plane, int B, int Nq, int Nk, int H, float c, hipStream_t stream, int waves, int out_il) {
+                          uint16_t* out, int ldo, long long out_plane, int B, int Nq, int Nk, int H, float c, hipStream_t stream, int waves, int out_il, int fixref) {
     const int nw = waves == 8 ? 8 : 4;
-    dim3 grid(((Nq + nw * 32 - 1) / (nw * 32)) * H * B), block(nw * 64);
+    const dim3 grid(((Nq + nw * 32 - 1) / (nw * 32)) * H * B), block(nw * 64);
     if (nw == 8) hipLaunchKernelGGL(attn_x3_pw_kernel<8>, grid, block, 0, stream, q, ldq, q_plane, k, v, ldkv, in_plane, out, ldo, out_plane, Nq, Nk, H, c, out_il);
+    else if (fixref) hipLaunchKernelGGL((attn_x3_pw_kernel<4, true>), grid, block, 0, stream, q, ldq, q_plane, k, v, ldkv, in_plane, out, ldo, out_plane, Nq, Nk, H, c, out_il);
     else hipLaunchKernelGGL(attn_x3_pw_kernel<4>, grid, block, 0, stream, q, ldq, q_plane, k, v, ldkv, in_plane, out, ldo, out_plane, Nq, Nk, H, c, out_il);
     return 0;
 }
