@@ -76,7 +76,7 @@ class _Ms:
         return other.ms - self.ms
 
 
-def instrumented_steps(run, reps: int = 3):
+def instrumented_steps(run, reps: int = 3, concurrent: bool = False):
     """`reps` instrumented steps (HIP events around every C-ABI launch, on the launch stream of the launching thread); per launch -- the steps
     issue the same launches in the same order ON EACH STREAM -- the MEDIAN duration over the steps.  One step alone carries first-touch outliers (the
     single-stream workspace is first used here: one QKV launch of 24 at 600 us moved that shape's average from 133 to 160 us in a round-5 run).
@@ -87,7 +87,7 @@ def instrumented_steps(run, reps: int = 3):
 
     per_step = []
     for _ in range(reps):
-        _hip.TIMER = _hip.KernelTimer()
+        _hip.TIMER = _hip.KernelTimer(concurrent=concurrent)
         try:
             run()
             _torch.cuda.synchronize()
@@ -118,7 +118,7 @@ def pipeline_families(model, src, tgt, wall_ms: float) -> dict:
     launch on its own stream, per-launch medians.  Launches of different streams overlap in time, so a family's summed launch time is NOT its
     share of the step: `frac` here = algorithmic work / summed launch durations / peak is the rate a launch sustains WHILE SHARING the chip with
     the other stream's kernels, and `sum_ms / wall` says how much of it overlapped."""
-    summ, records = instrumented_steps(lambda: model.predict_correspondences_batched(src, tgt))
+    summ, records = instrumented_steps(lambda: model.predict_correspondences_batched(src, tgt), concurrent=True)
     fam, total = {}, 0.0
     for name, d in summ.items():
         total += d["ms"]

@@ -164,6 +164,13 @@ int ufm_hint_concurrent_stream(void* stream, int on);
 int ufm_debug_set_gemm_variant(int variant);
 int ufm_debug_set_gemm_flags(int flags);
 int ufm_debug_set_gemm_tile_rows(int rows);
+/* Lab (round 6): deterministic 2-way split-K of the read-modify-write launches of ufm_gemm_bf16 (fp32 residual in place: proj / fc2) on `stream`:
+ * while the stream has a workspace, such launches with K >= min_k (K % 128 == 0, N % 256 == 0) run two workgroups per 256 x 256 tile, one per K
+ * half; the second to arrive (agent-scope arrival counter) adds the two fp32 partial tiles in half order and runs the epilogue.  The cut is at
+ * K / 2 -- a function of the layer alone, never of M -- so a row's bits do not depend on its batch neighbours; they differ from the unsplit sum's
+ * last bits.  ws: >= 64 KiB of ZEROED counters + tiles x 512 KiB; ws = NULL removes the stream's entry.  An A/B arm (tools/lab/gemm_splitk_ab.py,
+ * profiles/r06/gemm_splitk_ab.log), not a dispatch rule. */
+int ufm_debug_set_gemm_splitk(void* stream, void* ws, long long bytes, int min_k);
 /* The lab flag words' field tables (ufm_amd/csrc/lab_flags.h: ONE table of {name, shift, width} per word, pairwise disjoint at compile
  * time; every consumer reads its field masked to its width; the two setters return UFM_ERR_ARG for any bit outside the table).
  * word 0 = ufm_debug_set_gemm_flags, word 1 = ufm_debug_set_conv_variant; index 0.. until UFM_ERR_ARG.  Host only, no GPU call. */

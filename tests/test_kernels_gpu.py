@@ -196,6 +196,43 @@ def test_gemm_auto_dispatch_on_the_pipeline_shapes_bitwise_equals_128_kernel(hip
         lib.ufm_debug_set_gemm_flags(0)
 
 
+def test_gemm_lab_splitk_is_deterministic_and_batch_invariant(hip):
+    """Round 6 lab arm (ufm_debug_set_gemm_splitk): the read-modify-write launch as two K halves per 256 x 256 tile, the second
+    workgroup to arrive adds the halves in half order.  The cut (K / 2) depends on the layer only: (i) repeated launches agree bit for bit whoever
+    arrives last, (ii) the first rows of a large batch equal the same rows computed alone (batch invariance), (iii) against the unsplit kernel the
+    result differs in the last bits only, (iv) the counters are left zero (a second launch on the same workspace works)."""
+    import ctypes as C
+
+    lib = hip.lib()
+    N, K = 1024, 4096
+    M_big, M_small = 10960, 2740
+    A = bf16r(rnd(M_big, K, seed=1)).to(DEV).bfloat16()
+    W = bf16r(rnd(N, K, seed=2, scale=K**-0.5)).to(DEV).bfloat16()
+    bias, gamma = rnd(N, seed=3, scale=0.1).to(DEV), (1.0 + rnd(N, seed=7, scale=0.2)).to(DEV)
+    res0 = rnd(M_big, N, seed=9).to(DEV)
+    st = torch.cuda.current_stream()
+    ws = torch.zeros((65536 + 200 * 2 * 262144) // 4, device=DEV)
+
+    def run(M):
+        o = res0[:M].clone()
+        hip.gemm_bf16(A[:M], W, M, N, K, o, bias=bias, gamma=gamma, res=o)
+        return o
+
+    plain = run(M_big)
+    try:
+        assert lib.ufm_debug_set_gemm_splitk(C.c_void_p(st.cuda_stream), C.c_void_p(ws.data_ptr()), ws.numel() * 4, 3072) == 0
+        a = run(M_big)
+        for rep in range(4):
+            assert torch.equal(run(M_big), a), rep
+        small = run(M_small)
+        assert torch.equal(small, a[:M_small])
+        assert int(ws[:16384].view(torch.int32).abs().sum()) == 0
+    finally:
+        assert lib.ufm_debug_set_gemm_splitk(C.c_void_p(st.cuda_stream), None, 0, 256) == 0
+    assert not torch.equal(a, plain) and (a - plain).abs().max().item() <= 2e-5 * plain.abs().max().item()
+    assert torch.equal(run(M_big), plain)  # entry removed: the unsplit kernel again
+
+
 def test_concurrent_stream_hint_changes_the_dispatch_not_the_bits(hip):
     """ufm_hint_concurrent_stream (round 5): on a flagged stream launches of 8192 rows or more use full-height 8-phase tiles only (CU time
     instead of latency as the objective).  Same arithmetic in the same order: the read-modify-write proj shape at micro-batch rows (172 tiles

@@ -25,6 +25,7 @@ FAM = {"gemm_bf16": "ufm_gemm_bf16", "attn_bf16_kernel": "ufm_attention_bf16", "
        "layernorm_kernel": "ufm_layernorm", "upsample": "ufm_upsample_bilinear_nhwc", "dpt_tail_fused": "ufm_dpt_tail_fused", "head_tail_kernel": "ufm_head_tail",
        "patchify": "ufm_patchify", "unmap": "ufm_unmap", "conv_f32": "ufm_conv2d_nhwc_f32"}
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
+by_grid = collections.defaultdict(lambda: collections.defaultdict(list))  # round 6: (family, kernel template, grid) -> counter -> values: a grid size identifies a GEMM / conv shape
 for d in ("pmc_step_fetch", "pmc_step_write", "pmc_step_util"):
     files = sorted(glob.glob(f"gpurun_out/{d}/*/*counter_collection.csv"), key=os.path.getmtime)
     for f in files[-1:]:  # gpurun_out/ keeps earlier calls' files: only the newest pass counts
@@ -32,6 +33,9 @@ for d in ("pmc_step_fetch", "pmc_step_write", "pmc_step_util"):
             fam = next((v for k, v in FAM.items() if k in r["Kernel_Name"]), None)
             if fam:
                 acc[fam][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                if fam in ("ufm_gemm_bf16", "ufm_conv2d_nhwc_bf16x3"):
+                    short = r["Kernel_Name"].split("(")[0].replace("(anonymous namespace)::", "").replace("void ", "")[:60]
+                    by_grid[(fam, short, r.get("Grid_Size", r.get("Grid_Size_X", "?")))][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for fam, d in acc.items():
     a = {k: sum(v) / len(v) for k, v in d.items()}
@@ -51,6 +55,18 @@ for fam, d in acc.items():
         e["wave_wait_frac"] = a["SQ_WAIT_ANY"] / a["SQ_WAVE_CYCLES"]
         e["lds_bank_conflict_cycles"] = a["SQ_LDS_BANK_CONFLICT"]
     res[fam] = e
+# per (kernel, grid) table of the two big families: which launches carry the bytes above the algorithmic ones
+tab = []
+for (fam, short, grid), d in by_grid.items():
+    if "FETCH_SIZE" not in d:
+        continue
+    n = len(d["FETCH_SIZE"])
+    tab.append({"family": fam, "kernel": short, "grid": grid, "launches_per_step": round(n / STEPS, 2),
+                "read_mb_per_launch": round(sum(d["FETCH_SIZE"]) / n * 1024 * 2 / 1e6, 2),
+                "write_mb_per_launch": round(sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"]) * 1024 / 1e6, 2) if d.get("WRITE_SIZE") else None,
+                "read_gb_per_step": round(sum(d["FETCH_SIZE"]) * 1024 * 2 / STEPS / 1e9, 3)})
+tab.sort(key=lambda e: -e["read_gb_per_step"])
+res["_by_kernel_and_grid"] = tab
 try:
     commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
 except Exception:

@@ -184,6 +184,30 @@ extern "C" int ufm_debug_set_gemm_stamps(unsigned long long* buf, int rows) {
     g_gemm_stamp_rows = rows;
     return UFM_OK;
 }
+// Lab (round 6): per-stream workspaces for the deterministic 2-way split-K of the read-modify-write launches (proj / fc2).
+// While a stream has a workspace, its fp32-residual launches with K >= min_k whose dispatch is full-height 8-phase tiles run the split
+// form (gemm_bf16_8ph.hip, SK).  ws = NULL removes the stream's entry.  One workspace per CONCURRENT stream: launches on one stream are
+// ordered, so they can share it.  ws layout: [16384 x u32 counters, zero][tiles x 2 x 256 KiB partial tiles].
+struct SplitKWs {
+    void* stream;
+    char* ws;
+    long long bytes;
+    int min_k;
+};
+static SplitKWs g_splitk_ws[8] = {};
+extern "C" int ufm_debug_set_gemm_splitk(void* stream, void* ws, long long bytes, int min_k) {
+    UFM_REQUIRE(!ws || (bytes >= (1ll << 20) && ((uintptr_t)ws % 16) == 0 && min_k >= 256), "ufm_debug_set_gemm_splitk: a workspace of >= 1 MiB, 16-byte aligned, min_k >= 256");
+    for (auto& e : g_splitk_ws)
+        if (e.ws && e.stream == stream) e = SplitKWs{};
+    if (!ws) return UFM_OK;
+    for (auto& e : g_splitk_ws)
+        if (!e.ws) {
+            e = SplitKWs{stream, (char*)ws, bytes, min_k};
+            return UFM_OK;
+        }
+    ufm_set_error("ufm_debug_set_gemm_splitk: more than 8 streams with a workspace");
+    return UFM_ERR_ARG;
+}
 extern "C" int ufm_debug_set_gemm_flags(int flags) {
     // fields: lab_flags.h gemm_lab::ALL (one table; disjoint at compile time); a bit outside the table is refused, not dropped
     const unsigned unknown = (unsigned)flags & ~lab_known(gemm_lab::ALL);
@@ -344,6 +368,21 @@ extern "C" int ufm_gemm_bf16_rope(const uint16_t* A, int lda, const uint16_t* W,
         const long long short_of = (NCU - tiles % NCU) % NCU;  // the hybrid split's lead part is whole rounds less at most ntn - 1 tiles (whole tile ROWS)
         return persist_able(q) && tiles + short_of >= 2 * NCU && short_of < ntn && !lab_get(g_gemm_flags, gemm_lab::NO_PERSIST);
     };
+    // lab split-K (ufm_debug_set_gemm_splitk): this stream has a workspace -> its read-modify-write launches of K >= min_k run as two K halves
+    // per full-height 8-phase tile, whatever the cost model above chose (an A/B arm, not a dispatch rule)
+    if (epi == 3 && ok8 && !p.stamps && K % 128 == 0) {
+        for (const auto& e : g_splitk_ws) {
+            const long long tiles = (long long)((M + 255) / 256) * (N / 256);
+            if (e.ws && e.stream == stream && K >= e.min_k && tiles <= 16384 && 65536 + tiles * 2 * 262144 <= e.bytes) {
+                GemmArgs q = p;
+                q.splitk = 2, q.counters = (unsigned*)e.ws, q.slab = (float*)(e.ws + 65536);
+                if (ufm_launch_gemm_8ph(q, out_dtype, (hipStream_t)stream, 8, epi) == 0) {
+                    UFM_CHECK_LAUNCH("ufm_gemm_bf16");
+                    return UFM_OK;
+                }
+            }
+        }
+    }
     if (variant == 7) {  // tests / tools: the persistent kernel wherever it can run at all (any tile count), else the 8-phase kernel
         if (persist_able(p)) {
             ufm_launch_gemm_8ph_persist(p, (hipStream_t)stream, epi, NCU);

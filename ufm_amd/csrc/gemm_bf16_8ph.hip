@@ -35,7 +35,7 @@ using IC = std::integral_constant<int, K>;
 // of it; its second 64-row half simply has NF - 4 fragments).  Lower tiles make ceil(M / height) * (N / 256) fit whole rounds of
 // the chip where 256-row tiles would strand CUs (M = 10 952, N = 1024: 172 tiles on 256 CUs -> 232 tiles of 192 rows).  The
 // staging, the phase schedule and every output element's accumulation order are those of NF = 8.
-template <int OUT_BF16, int NF, int EPI, bool STAMP = false>
+template <int OUT_BF16, int NF, int EPI, bool STAMP = false, bool SK = false>
 __device__ __forceinline__ void gemm_bf16_8ph_body(const GemmArgs& p, char* smem) {
     static_assert(NF >= 5 && NF <= 8, "NF");
     GemmStamps stamps;
@@ -47,7 +47,9 @@ __device__ __forceinline__ void gemm_bf16_8ph_body(const GemmArgs& p, char* smem
 
     // ---- tile of this block: XCD chunking + grouped rasterization (as gemm_bf16.hip) ----
     const int ntn = p.N >> 8, ntm = (p.M - p.m_begin + BMT - 1) / BMT;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    // SK: workgroups 2 v and 2 v + 1 (neighbours in launch order: they run side by side) are the two K halves of output tile v
+    const int half_k = SK ? (int)(blockIdx.x & 1) : 0;
+    const int bid = SK ? xcd_remap(blockIdx.x >> 1, gridDim.x >> 1) : xcd_remap(blockIdx.x, gridDim.x);
     // grouped rasterization height (tools/lab/gemm_gm_probe.py: flag bits 8..15); 8 vs 4: QKV -8 %, others +-1 %.  (Until late in round 5 this read ALL bits above 8: every A/B arm
     // that set one of the later lab flags -- bits 16..28 -- also ran this kernel column-major, GM = 2^k; the affected logs say so.)
     const int GM = lab_get(p.debug, gemm_lab::RASTER_GROUP) ? lab_get(p.debug, gemm_lab::RASTER_GROUP) : 8;
@@ -55,7 +57,9 @@ __device__ __forceinline__ void gemm_bf16_8ph_body(const GemmArgs& p, char* smem
     const int grp = bid / per_group, in_g = bid - grp * per_group;
     const int gm = min(GM, ntm - grp * GM);
     const int m0 = p.m_begin + (grp * GM + in_g % gm) * BMT, n0 = (in_g / gm) << 8;
-    const int nt = p.K >> 6;
+    const int nt_all = p.K >> 6;
+    const int kt0 = SK ? half_k * (nt_all >> 1) : 0;                       // first K-tile of this workgroup
+    const int nt = SK ? (half_k ? nt_all - (nt_all >> 1) : (nt_all >> 1)) : nt_all;
     if (lab_get(p.debug, gemm_lab::STAGGER) & 7) {  // lab (tools/lab/epi_contention.py): first-round blocks start (block / 8) % 4 x units x ~1 us apart
         if (blockIdx.x < 256) {
             const int units = (lab_get(p.debug, gemm_lab::STAGGER) & 7) * (int)((blockIdx.x >> 3) & 3);
@@ -74,8 +78,8 @@ __device__ __forceinline__ void gemm_bf16_8ph_body(const GemmArgs& p, char* smem
         for (int h = 0; h < 2; ++h) {
             const int brow = (lr >> 6) * RW + h * 64 + (lr & 63);   // X half h: rows mh = h of both wave groups (rows past RW: unused)
             const int bcol = (lr >> 5) * 64 + h * 32 + (lr & 31);   // W half h: columns nh = h of the four wave columns
-            xsrc[h][i] = 2u * ((unsigned)min(m0 + brow, p.M - 1) * (unsigned)p.lda + chunk);  // BYTE offsets: the DMA
-            wsrc[h][i] = 2u * ((unsigned)(n0 + bcol) * (unsigned)p.ldw + chunk);               // address is sgpr base + vgpr32
+            xsrc[h][i] = 2u * ((unsigned)min(m0 + brow, p.M - 1) * (unsigned)p.lda + chunk) + (unsigned)kt0 * 128u;  // BYTE offsets: the DMA
+            wsrc[h][i] = 2u * ((unsigned)(n0 + bcol) * (unsigned)p.ldw + chunk) + (unsigned)kt0 * 128u;               // address is sgpr base + vgpr32
         }
     }
     auto stage = [&](auto kind, int tile) {  // kind: 0 W-lo, 1 X-lo, 2 W-hi, 3 X-hi
@@ -214,14 +218,57 @@ __device__ __forceinline__ void gemm_bf16_8ph_body(const GemmArgs& p, char* smem
         if (keep == 123.456f) ((float*)p.out)[0] = keep;
         return;
     }
+    if constexpr (SK) {
+        // ---- 2-way split-K combine (cdna_hip_programming.md section 5, "In-launch split-K reduction"; the machinery of conv_bf16x3.hip):
+        // plain 16-byte slab stores in fragment order -> every wave drains -> barrier -> one lane: agent release, drain, ticket ----
+        constexpr int TILE_F = 256 * 256;
+        float* const tile_slab = p.slab + (size_t)bid * 2 * TILE_F;
+        float* const mine = tile_slab + (size_t)half_k * TILE_F + (wave * 32) * 256 + lane * 4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) *(f32x4*)(mine + ((h * 4 + n) * 4 + m) * 256) = acc[h][n][m];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* const flag = (unsigned*)smem;  // the staging buffers are idle: word 0 carries the ticket to all waves
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            *flag = __hip_atomic_fetch_add(p.counters + bid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        const unsigned ticket = *flag;
+        if (ticket != 1u) return;  // the first arriver of this tile is done
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(p.counters + bid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+        }
+        __syncthreads();
+        // the two partial tiles added in HALF order (this workgroup's own one re-read like the other): the same bits whoever came last
+        const float* src = tile_slab + (wave * 32) * 256 + lane * 4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const f32x4 a = *(const f32x4*)(src + ((h * 4 + n) * 4 + m) * 256);
+                    const f32x4 b = *(const f32x4*)(src + TILE_F + ((h * 4 + n) * 4 + m) * 256);
+                    acc[h][n][m] = a + b;
+                }
+        __syncthreads();  // `flag` (smem word 0) has been read by every wave before the epilogue re-uses the buffer
+    }
     epilogue_two_slices<OUT_BF16, RW - 64, EPI>(p, acc[0], acc[1], smem + wave * 16384, m0 + wr * RW, n0 + wc * 64, lane);
     if constexpr (STAMP) stamps.finish(p.stamps, p.stamp_rows);
 }
 
-template <int OUT_BF16, int NF, int EPI, bool STAMP = false>
+template <int OUT_BF16, int NF, int EPI, bool STAMP = false, bool SK = false>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_8ph_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[8 * HALF];  // [tile & 1][kind]
-    gemm_bf16_8ph_body<OUT_BF16, NF, EPI, STAMP>(p, smem);
+    gemm_bf16_8ph_body<OUT_BF16, NF, EPI, STAMP, SK>(p, smem);
 }
 
 }  // namespace
@@ -230,6 +277,11 @@ int ufm_launch_gemm_8ph(const GemmArgs& p, int out_dtype, hipStream_t stream, in
     const int bmt = 32 * nf;
     const int ntm = (p.M - p.m_begin + bmt - 1) / bmt, ntn = p.N / 256;
     dim3 grid(ntm * ntn), block(512);
+    if (p.splitk == 2) {  // lab (ufm_debug_set_gemm_splitk): the read-modify-write form only, full-height tiles, K >= 256 (each half: >= 2 K-tiles)
+        if (out_dtype != UFM_F32 || epi != 3 || nf != 8 || (p.K >> 6) < 4) return 1;
+        hipLaunchKernelGGL((gemm_bf16_8ph_kernel<0, 8, 3, false, true>), dim3(2 * ntm * ntn), block, 0, stream, p);
+        return 0;
+    }
     if (p.stamps && (nf == 6 || nf == 8) && ((out_dtype == UFM_BF16 && epi == 1) || (out_dtype == UFM_F32 && epi == 3))) {  // diagnostic build
         if (nf == 6 && epi == 1) hipLaunchKernelGGL((gemm_bf16_8ph_kernel<1, 6, 1, true>), grid, block, 0, stream, p);
         else if (nf == 6) hipLaunchKernelGGL((gemm_bf16_8ph_kernel<0, 6, 3, true>), grid, block, 0, stream, p);

@@ -22,6 +22,13 @@ struct GemmArgs {
     // diagnostic builds only (ufm_debug_set_gemm_stamps; the STAMP = true instantiations): 8 x uint64 per workgroup, see gemm_stamp_row
     unsigned long long* stamps;
     int stamp_rows;
+    // round 6 (lab: ufm_debug_set_gemm_splitk): deterministic 2-way split of the K loop of a read-modify-write launch -- workgroups 2 v and
+    // 2 v + 1 compute the two halves of output tile v, each parks its fp32 partial tile in `slab` (fragment order), the second to arrive (an
+    // agent-scope arrival counter per tile) adds the two in HALF order and runs the epilogue.  The cut is at K / 2: it depends on the layer
+    // alone, so a row's bits do not depend on its batch neighbours.  0 / 1 = off.
+    int splitk;
+    float* slab;          // [tiles][2][256 * 256] partial tiles
+    unsigned* counters;   // [tiles], zero between launches (the last arriver resets its word)
 };
 
 namespace {

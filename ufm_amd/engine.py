@@ -877,7 +877,7 @@ class Engine:
         # hipGraph capture) while this stream does level 3 and starts the fusion; every side stream is joined back right before
         # its level is read.  Bit-identical (same kernels on the same buffers).
         cur = torch.cuda.current_stream(self.dev)
-        use_ls = self.level_streams and Bt <= self.level_streams_max_images and hip.TIMER is None
+        use_ls = self.level_streams and Bt <= self.level_streams_max_images and not hip.timer_serialises()
         if use_ls and fork_from is None and torch.cuda.is_current_stream_capturing():
             # Under hipGraph capture a fork from an ALREADY FORKED stream segfaults inside hipStreamEndCapture (ROCm 7.0 / 7.2 runtime,
             # profiles/r04/capture_nested_fork.log).  If this call runs on one of the engine's own forked streams (a head stream, a
@@ -1110,7 +1110,7 @@ class Engine:
         B = src.shape[0]
         if symmetrized and (B % 2 != 0 or (Hs, Ws) != (Ht, Wt)):
             raise ValueError("symmetrized=True needs an even number of equally sized pairs: (a,b),(b,a),... (ufm.py:336-352)")
-        nmb = self.micro_batches if (B >= 2 * self.micro_batches and hip.TIMER is None and not symmetrized) else 1
+        nmb = self.micro_batches if (B >= 2 * self.micro_batches and not hip.timer_serialises() and not symmetrized) else 1
         if nmb == 1:
             self._tls.ns = ""
             return self._forward_images(src, tgt, layout, scale3, shift3, H, W, Hs, Ws, Ht, Wt, symmetrized)
@@ -1373,7 +1373,7 @@ class Engine:
             conc = self.concurrent_heads if self.concurrent_heads is not None else getattr(self._tls, "ns", "") == ""
         if conc is None:
             pass
-        elif len(self.heads) > 1 and conc and hip.TIMER is None:
+        elif len(self.heads) > 1 and conc and not hip.timer_serialises():
             # the heads only share their (read-only) input pyramid: run them on separate HIP streams so the
             # latency-bound small-grid layers of one overlap the large layers of the other
             main = torch.cuda.current_stream(self.dev)

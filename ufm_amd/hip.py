@@ -42,6 +42,7 @@ SIGNATURES = {
     "ufm_debug_set_gemm_variant": [_i],
     "ufm_debug_set_gemm_flags": [_i],
     "ufm_debug_set_gemm_tile_rows": [_i],
+    "ufm_debug_set_gemm_splitk": [_vp, _vp, C.c_longlong, _i],
     "ufm_debug_lab_field": [_i, _i, C.POINTER(C.c_char_p), _ip, _ip],
     "ufm_debug_set_gemm_stamps": [_vp, _i],
     "ufm_debug_set_conv_stamps": [_vp, _i],
@@ -117,7 +118,10 @@ class KernelTimer:
     Events are recorded on the stream the kernels are launched on (torch's current stream OF THE CALLING THREAD: the engine's two
     micro-batch workers each bracket their own launches on their own stream; `streams[i]` is the raw handle records[i] ran on)."""
 
-    def __init__(self):
+    def __init__(self, concurrent: bool = False):
+        # concurrent=False (default): the engine runs single-stream while the timer is set (launch durations do not overlap: the per-kernel
+        # roofline leg); True: the engine keeps its micro-batch / head streams (the timed configuration; durations overlap across streams)
+        self.concurrent = concurrent
         self.records = []  # (name, start_event, end_event, meta)
         self.streams = []  # raw stream handle of each record
         self._tl = threading.local()
@@ -156,6 +160,11 @@ class KernelTimer:
 
 
 TIMER: Optional[KernelTimer] = None
+
+
+def timer_serialises() -> bool:
+    """True while a KernelTimer that wants non-overlapping launches is set: the engine then runs one stream."""
+    return TIMER is not None and not TIMER.concurrent
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _cur_device = getattr(torch._C, "_cuda_getDevice", None)
