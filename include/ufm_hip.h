@@ -325,6 +325,12 @@ int ufm_conv2d_nhwc_bf16x3_grouped(const uint16_t* in, int groups, int in_shared
                                    const float* bias, int act, const uint16_t* res1, const uint16_t* res2, int shuffle,
                                    uint16_t* out, uint16_t* out_relu, const uint16_t* zero_page, int passes,
                                    void* splitk_ws /* may be NULL */, long long splitk_ws_bytes, void* stream);
+/* Round 6: an INTERLEAVED copy of a convolution's split weights -- [groups * Cout][KH * KW * Cin / 32][hi 32 | lo 32], the values of the planar
+ * [2][groups * Cout][KH * KW * Cin] tensor `planar` -- registered against that tensor's address.  Launches of ufm_conv2d_nhwc_bf16x3(_grouped) whose
+ * `weight` is `planar` and that run on the row-window halo kernel (3x3 / stride 1 / pad 1 layers on the 8-phase tile) stage W from the copy:
+ * whole 128-byte LDS-DMA rows.  Results are bitwise the same.  il = NULL removes the entry; the caller removes it before freeing either
+ * buffer.  At most 512 entries.  Host only. */
+int ufm_conv_x3_register_interleaved_weights(const void* planar, const void* il);
 /* Deterministic split-K.  With a workspace (zero-filled when allocated; the kernel leaves its counters zero again) the K loop of
  * the small-map, long-K layers (<= 1600 output pixels per image and >= 48 K-tiles of 32 channels: the 19^2 / 37^2 layers of the DPT
  * heads) is cut into 2-6 consecutive ranges, one workgroup each; fp32 partial tiles meet in the workspace and the last workgroup

@@ -203,7 +203,7 @@ def test_lab_flag_words_have_one_disjoint_table_and_refuse_unknown_bits(lib):
     assert lib.ufm_debug_set_conv_variant(5) == -1 and lib.ufm_debug_set_conv_variant(2 | (4 << 8)) == -1 and lib.ufm_debug_set_conv_variant(2 | (6 << 8)) == 0
     lib.ufm_debug_set_conv_variant(0)
     assert lib.ufm_debug_set_upsample_variant(4) == -1 and lib.ufm_debug_set_upsample_variant(1) == 0
-    assert lib.ufm_debug_set_attn_variant(8) == -1 and lib.ufm_debug_set_attn_variant(0) == 0
+    assert lib.ufm_debug_set_attn_variant(16) == -1 and lib.ufm_debug_set_attn_variant(8) == 0 and lib.ufm_debug_set_attn_variant(0) == 0
     # no consumer decodes a lab word by hand: every read of GemmArgs::debug / the two globals goes through lab_get / lab_mask
     csrc = os.path.join(REPO, "ufm_amd", "csrc")
     for f in sorted(os.listdir(csrc)):

@@ -1490,16 +1490,25 @@ def test_conv2d_bf16x3_halo_bit_identical(hip, B, H, W, Cin, Cout, act, nres, gr
     outs = {}
     HALO_OFF = 1 << 5
     variants = (19, 2 | HALO_OFF, 2, 0, 2 | (5 << 8), 2 | (6 << 8), 2 | (7 << 8), 2 | (7 << 8) | HALO_OFF)
+    # ... and every halo arm once more with the weights staged from their INTERLEAVED copy (ufm_conv_x3_register_interleaved_weights: whole
+    # 128-byte DMA rows; keys 1000 + variant)
+    w_il = hip.interleave_split(w.view(2, G * Cout, 9 * Cin))
     try:
-        for variant in variants:
-            assert lib.ufm_debug_set_conv_variant(variant) == 0
-            out = torch.full(oshape, 7.0, device=DEV, dtype=torch.bfloat16)
-            orl = torch.full(oshape, 7.0, device=DEV, dtype=torch.bfloat16)
-            hip.conv2d_x3(x, B, H, W, Cin, w, Cout, 3, 3, 1, 1, out, zero, bias=b, act=act, res1=res[0], res2=res[1], out_relu=orl, groups=G)
-            outs[variant] = (out.view(torch.int16).clone(), orl.view(torch.int16).clone())
+        for wil in (False, True):
+            if wil:
+                assert lib.ufm_conv_x3_register_interleaved_weights(w.data_ptr(), w_il.data_ptr()) == 0
+            for variant in variants:
+                if wil and (variant == 19 or variant & HALO_OFF):
+                    continue
+                assert lib.ufm_debug_set_conv_variant(variant) == 0
+                out = torch.full(oshape, 7.0, device=DEV, dtype=torch.bfloat16)
+                orl = torch.full(oshape, 7.0, device=DEV, dtype=torch.bfloat16)
+                hip.conv2d_x3(x, B, H, W, Cin, w, Cout, 3, 3, 1, 1, out, zero, bias=b, act=act, res1=res[0], res2=res[1], out_relu=orl, groups=G)
+                outs[variant + (1000 if wil else 0)] = (out.view(torch.int16).clone(), orl.view(torch.int16).clone())
     finally:
         lib.ufm_debug_set_conv_variant(0)
-    for v in variants[1:]:
+        assert lib.ufm_conv_x3_register_interleaved_weights(w.data_ptr(), None) == 0
+    for v in [k for k in outs if k != 19]:
         assert torch.equal(outs[19][0], outs[v][0]), (v, int((outs[19][0] != outs[v][0]).sum()))
         assert torch.equal(outs[19][1], outs[v][1]), v
     # ... and the numbers are a convolution: against the fp64 statement on the split operands (first group)

@@ -14,6 +14,8 @@
 //     source address (gather + zero halo via per-lane source, as in conv_f32.hip) and to the reads.
 //   * ReLU-on-input uses the sign of hi for both halves (packed 16-bit ops on the fragments).
 //   * epilogue: bias, act, two split residuals, split (hi, lo) store, pixel-shuffle store.
+#include <mutex>
+
 #include "conv_x3_common.h"
 
 namespace {
@@ -258,6 +260,35 @@ static int g_conv_variant_all = 0;
 // test/tuning hook: 0 = auto, 1 = 128-row kernels only, 2 = 8-phase kernel wherever it is applicable,
 // 3 = 128-row kernels only and never the deep (NS = 4) ring; + 16 = the serial (per-pass) residual read-out of rounds 1-4;
 // bits 8..11 = pinned 8-phase tile height; bits 12..18 (with stamps set) = timing ablations of the 8-phase loop (ConvX3Args::ablate); bits 19 / 20 = the latency / the CU-time objective of the tile-height choice on every stream (default: by ufm_hint_concurrent_stream)
+// Interleaved copies of convolution weights (round 6): a caller that holds, beside the planar split weights [2][G Cout][KH KW Cin] it passes to
+// ufm_conv2d_nhwc_bf16x3(_grouped), the same values interleaved per 32-channel chunk -- [G Cout][KH KW Cin / 32][hi 32 | lo 32] -- registers the
+// pair here; launches whose `weight` pointer is registered and that run on the halo kernel then stage W from the interleaved copy (whole 128-byte
+// DMA rows).  The caller owns both buffers and removes the entry (il = NULL) before freeing either.  Bitwise the same results.
+struct WilEntry {
+    const void* planar;
+    const uint16_t* il;
+};
+static WilEntry g_wil[512] = {};
+static std::mutex g_wil_mutex;
+extern "C" int ufm_conv_x3_register_interleaved_weights(const void* planar, const void* il) {
+    UFM_REQUIRE(planar && ((uintptr_t)il % 16) == 0, "ufm_conv_x3_register_interleaved_weights: null / misaligned pointer");
+    std::lock_guard<std::mutex> lock(g_wil_mutex);
+    for (auto& e : g_wil)
+        if (e.planar == planar) e = WilEntry{};
+    if (!il) return UFM_OK;
+    for (auto& e : g_wil)
+        if (!e.planar) {
+            e = WilEntry{planar, (const uint16_t*)il};
+            return UFM_OK;
+        }
+    ufm_set_error("ufm_conv_x3_register_interleaved_weights: table full (512 entries)");
+    return UFM_ERR_ARG;
+}
+static const uint16_t* conv_x3_wil_of(const void* planar) {
+    for (const auto& e : g_wil)  // (read without the lock: entries are written whole, by callers that are not launching on these weights)
+        if (e.planar == planar) return e.il;
+    return nullptr;
+}
 extern "C" int ufm_debug_set_conv_variant(int v) {
     // fields: lab_flags.h conv_lab::ALL (one table; disjoint at compile time); a bit outside the table is refused
     const unsigned unknown = (unsigned)v & ~lab_known(conv_lab::ALL);
@@ -366,9 +397,14 @@ static void launch_conv_x3(const ConvX3Args& p_in, int passes, hipStream_t strea
                       p.W >= 32 && (long long)(p.H - 2) * p.W >= 272 &&   // one column border per 16-pixel fragment; image boundaries further apart than a window + two rows
                       p.in_plane < (1ll << 29) && p.w_plane < (1ll << 29) &&  // 32-bit buffer offsets of both planes below 2^31 bytes
                       lab_get(g_conv_variant_all, conv_lab::HALO) != 1 && !p.ablate;
-    auto launch8 = [&](const ConvX3Args& q, int nf) {
-        if (halo) ufm_launch_conv_x3_halo(q, stream, nf);
-        else ufm_launch_conv_x3_8ph(q, stream, nf);
+    auto launch8 = [&](const ConvX3Args& q_, int nf) {
+        if (halo) {
+            ConvX3Args q = q_;
+            q.w_il = lab_get(g_conv_variant_all, conv_lab::HALO) == 2 ? nullptr : conv_x3_wil_of(q.w);  // HALO = 2: the planar W staging (A/B)
+            ufm_launch_conv_x3_halo(q, stream, nf);
+        } else {
+            ufm_launch_conv_x3_8ph(q_, stream, nf);
+        }
     };
     // 256 px x 128 cout pair tile (round 5): Cout a multiple of 128 but not of 256 (the heads' p_conv1, 296^2 x 256 -> 128) on grids of at
     // least one workgroup per CU.  g_conv_variant 4 = wherever it applies (tests), 1 / 3 = never.

@@ -68,7 +68,10 @@ struct Sched {
     }
 };
 
-template <int NF = 8, bool STAMP = false>
+// WIL: the weights are INTERLEAVED per 32-channel chunk, [Cout][9 Cin / 32][hi 32 | lo 32] (ConvX3Args::w_il, packed beside the planar copy): a W piece
+// is then 8 couts x one whole 128-byte line instead of 16 couts x 64 B of one plane; LDS half-tile [128 couts][128 B], chunk 4 plane + fq at
+// position ^ (cout & 7) (the layout of ufm_gemm_bf16x3_il).  Same operands in the same MFMAs.
+template <int NF = 8, bool STAMP = false, bool WIL = false>
 __global__ __launch_bounds__(512, 1) void conv_x3_halo_kernel(ConvX3Args p) {
     static_assert(NF >= 5 && NF <= 8, "NF");
     constexpr int WC = 4;
@@ -121,9 +124,13 @@ __global__ __launch_bounds__(512, 1) void conv_x3_halo_kernel(ConvX3Args p) {
     const int e_bound = b_near * HW - (m0 - 1);              // window coordinate of that image boundary (may lie outside the window)
     const bool b_first = b_near == 0, b_last = b_near == p.B;
     const int wlr = wave * 16 + srow;
-    const unsigned w_src = 2u * ((unsigned)(n0 + (wlr >> 5) * 64 + (wlr & 31)) * ktot + (unsigned)((slot ^ swz(wlr)) * 8));  // W half 0 (couts nh = 0 of every wave column); half 1: + 32 couts
-    const unsigned w_half_b = 2u * 32u * ktot;
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w_g, 0, NUM_RECORDS, 0x00020000);
+    // WIL: piece = 8 couts x 128 B, wave w stages pieces w and 8 + w of a half: lane (l >> 3, l & 7) = cout row 8 piece + (l >> 3), position l & 7
+    const int wil_lr = wave * 8 + (lane >> 3);  // row of piece `wave` (piece 8 + wave: + 64 rows = + 2 wave columns = + 128 couts of the tile)
+    const unsigned w_src = WIL ? 2u * ((unsigned)(n0 + (wil_lr >> 5) * 64 + (wil_lr & 31)) * (2u * ktot) + (unsigned)(((lane & 7) ^ (wil_lr & 7)) * 8))
+                               : 2u * ((unsigned)(n0 + (wlr >> 5) * 64 + (wlr & 31)) * ktot + (unsigned)((slot ^ swz(wlr)) * 8));  // W half 0 (couts nh = 0 of every wave column); half 1: + 32 couts
+    const unsigned w_half_b = 2u * 32u * ktot * (WIL ? 2u : 1u);
+    const uint16_t* const w_base_g = WIL ? p.w_il + (size_t)grp * 2 * p.w_group : w_g;
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w_base_g, 0, NUM_RECORDS, 0x00020000);
     const unsigned w_plane_b = (unsigned)(2 * p.w_plane), x_plane_b = (unsigned)(2 * p.in_plane);
     struct TapIter {
         int tap, c0;
@@ -139,9 +146,15 @@ __global__ __launch_bounds__(512, 1) void conv_x3_halo_kernel(ConvX3Args p) {
         char* dst_lo = dst + WPLANE;
         if (!live) dst = dst_lo = smem + SCRAP;
         const unsigned voff = live ? w_src : OOB;
-        const unsigned soff = 2u * (unsigned)(ti.tap * p.Cin + ti.c0) + H * w_half_b;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, LDS_PTR(dst), 16, voff, soff, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, LDS_PTR(dst_lo), 16, voff, soff + w_plane_b, 0, 0);
+        if constexpr (WIL) {  // the K-tile's chunk is 64 elements [hi 32 | lo 32] of every cout row; second piece: couts + 128 (rows 64..127 of the half)
+            const unsigned soff = 4u * (unsigned)(ti.tap * p.Cin + ti.c0) + H * w_half_b;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, LDS_PTR(dst), 16, voff, soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, LDS_PTR(live ? dst + 8192 : dst), 16, voff, soff + 4u * w_half_b, 0, 0);
+        } else {
+            const unsigned soff = 2u * (unsigned)(ti.tap * p.Cin + ti.c0) + H * w_half_b;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, LDS_PTR(dst), 16, voff, soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, LDS_PTR(dst_lo), 16, voff, soff + w_plane_b, 0, 0);
+        }
         if (++ti.tap == 9) ti.tap = 0, ti.c0 += 32;
     };
     // hi and lo piece of slot s in {0, 1, 2} of window v = (chunk v / 3, filter row v % 3); PL: 0 = hi only, 1 = lo only, 2 = both
@@ -179,6 +192,9 @@ __global__ __launch_bounds__(512, 1) void conv_x3_halo_kernel(ConvX3Args p) {
         const int r = wc * 32 + fr;
         w_off = r * 64 + ((fq ^ swz(r)) << 4);  // (swz looks at bits 2..3 of the row: the same for rows r and r + 16)
     }
+    int wil_off[2];  // WIL: [plane]: row r at r * 128 B, chunk 4 plane + fq at position ^ (r & 7); (r & 7) = fr & 7 for both fragments
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) wil_off[pl] = (wc * 32 + fr) * 128 + (((4 * pl + fq) ^ (fr & 7)) << 4);
     // ---- column borders, wave-uniform: the x = 0 pixels of this wave row's RW pixels are W apart (W >= 32: at most one per 16-pixel fragment),
     // the x = W - 1 pixels sit right before them.  pres0 / pres1: bit f = fragment f (= 4 mh + i) holds an x = 0 / x = W - 1 pixel;
     // pos0 / pos1: its row fr in 4 bits per fragment.  A lane's mask is one compare of fr with a scalar. ----
@@ -217,8 +233,13 @@ __global__ __launch_bounds__(512, 1) void conv_x3_halo_kernel(ConvX3Args p) {
         const char* s = smem + TP * WTILE + NH * WHALF;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            w[j][0] = *(const bf16x8*)(s + w_off + j * 1024);
-            w[j][1] = *(const bf16x8*)(s + WPLANE + w_off + j * 1024);
+            if constexpr (WIL) {
+                w[j][0] = *(const bf16x8*)(s + wil_off[0] + j * 2048);
+                w[j][1] = *(const bf16x8*)(s + wil_off[1] + j * 2048);
+            } else {
+                w[j][0] = *(const bf16x8*)(s + w_off + j * 1024);
+                w[j][1] = *(const bf16x8*)(s + WPLANE + w_off + j * 1024);
+            }
         }
     };
     auto mma = [&](auto mh_, auto nh_, auto kw_, bf16x8 (&w)[2][2], bool fresh_x) {
@@ -349,6 +370,10 @@ int ufm_launch_conv_x3_halo(const ConvX3Args& p, hipStream_t stream, int nf) {
     const int ntm = (p.M - p.m_begin + rows - 1) / rows * p.groups;
     const dim3 grid(ntm * (p.Cout / 256)), block(512);
     if (p.stamps && nf == 8) hipLaunchKernelGGL((conv_x3_halo_kernel<8, true>), grid, block, 0, stream, p);  // diagnostic build
+    else if (p.w_il && nf == 5) hipLaunchKernelGGL((conv_x3_halo_kernel<5, false, true>), grid, block, 0, stream, p);
+    else if (p.w_il && nf == 6) hipLaunchKernelGGL((conv_x3_halo_kernel<6, false, true>), grid, block, 0, stream, p);
+    else if (p.w_il && nf == 7) hipLaunchKernelGGL((conv_x3_halo_kernel<7, false, true>), grid, block, 0, stream, p);
+    else if (p.w_il) hipLaunchKernelGGL((conv_x3_halo_kernel<8, false, true>), grid, block, 0, stream, p);
     else if (nf == 5) hipLaunchKernelGGL((conv_x3_halo_kernel<5>), grid, block, 0, stream, p);
     else if (nf == 6) hipLaunchKernelGGL((conv_x3_halo_kernel<6>), grid, block, 0, stream, p);
     else if (nf == 7) hipLaunchKernelGGL((conv_x3_halo_kernel<7>), grid, block, 0, stream, p);

@@ -35,6 +35,7 @@ struct ConvX3Args {
     int splitk;
     float* slab;          // [tiles][splitk][BM * BN] partial tiles (fragment order)
     unsigned* counters;   // [tiles], zero between launches (the last arriver resets its tile's word)
+    const uint16_t* w_il; // round 6: the same weights INTERLEAVED, [groups][Cout][KH KW Cin / 32][hi 32 | lo 32] (or null): read by the halo kernel in place of `w`
     int out_il;           // round 6: the split output is stored INTERLEAVED, [row][Cout / 32][hi 32 | lo 32] (UFM_BF16X2_IL; no residual, no out_relu, no shuffle)
     int il;               // round 6, ufm_gemm_bf16x3_il: `in` and `w` are INTERLEAVED split operands [rows][K / 32][hi 32 | lo 32] (the 8-phase Linear form only)
     int serial_epilogue;  // A/B hook (ufm_debug_set_conv_variant bit 4): the per-pass residual read-out of rounds 1-4

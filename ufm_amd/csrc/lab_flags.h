@@ -55,7 +55,7 @@ static_assert(lab_disjoint(ALL), "gemm lab flag fields overlap");
 namespace conv_lab {
 constexpr LabField KERNEL{"kernel", 0, 4};                // 0 auto, 1 = 128-row kernels, 2 = 8-phase wherever applicable, 3 = 128-row and never the deep ring, 4 = pair kernel wherever applicable
 constexpr LabField SERIAL_EPILOGUE{"serial_epilogue", 4, 1};  // "+ 16": the per-pass residual read-out of rounds 1-4 (A/B)
-constexpr LabField HALO{"halo", 5, 2};                    // round 6: 0 = the row-window halo form of the 8-phase 3x3 kernel wherever it applies, 1 = never (the gather form: A/B, tests)
+constexpr LabField HALO{"halo", 5, 2};                    // round 6: 0 = the row-window halo form of the 8-phase 3x3 kernel wherever it applies, 1 = never (the gather form: A/B, tests), 2 = the halo form with planar W staging even where an interleaved copy is registered (A/B)
 constexpr LabField NF_PIN{"nf_pin", 8, 4};                // pinned 8-phase tile height (5..8 fragments per wave row)
 constexpr LabField ABLATE{"ablate", 12, 7};               // timing ablations of the stamped 8-phase loop (ConvX3Args::ablate)
 constexpr LabField LATENCY{"latency_objective", 19, 1};

@@ -203,6 +203,22 @@ class _Conv:
             self.w = w.permute(0, 2, 3, 1).contiguous()
         if split:
             self.w = _split_bf16(self.w)
+            # round 6: the layers the row-window halo kernel serves (3x3 / stride 1 / pad 1 on the 256-cout 8-phase tile) also keep their weights
+            # INTERLEAVED per 32-channel chunk, registered against the planar tensor's address: the kernel then stages W as whole 128-byte lines
+            # (-2...-3 % per launch on top of the halo tile, profiles/r06/conv_halo_ab.log).  The entry leaves the library's table with this object.
+            if self.k == 3 and self.stride == 1 and self.pad == 1 and not self.shuffle and self.cout % 256 == 0 and self.cin % 32 == 0:
+                self.w_il = hip.interleave_split(self.w.view(2, self.cout, 9 * self.cin))
+                if hip.lib().ufm_conv_x3_register_interleaved_weights(self.w.data_ptr(), self.w_il.data_ptr()) == 0:
+                    weakref.finalize(self, _unregister_wil, self.w.data_ptr())
+                else:
+                    self.w_il = None  # table full: the planar staging (same results)
+
+
+def _unregister_wil(planar_ptr: int) -> None:
+    try:
+        hip.lib().ufm_conv_x3_register_interleaved_weights(planar_ptr, None)
+    except Exception:  # interpreter shutdown
+        pass
 
 
 def _lin_as_conv(lin: nn.Linear, dev) -> _Conv:

@@ -85,6 +85,7 @@ SIGNATURES = {
     "ufm_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
     "ufm_add_f32": [_vp, _vp, _vp, _i64, _vp],
 }
+SIGNATURES["ufm_conv_x3_register_interleaved_weights"] = [_vp, _vp]
 PLAIN = {"ufm_conv_x3_splitk_ws_bytes": (C.c_longlong, [C.c_int] * 10), "ufm_group_norm_ws_floats": (C.c_int, [C.c_int, C.c_int, C.c_int]), "ufm_abi_version": (C.c_int, []), "ufm_last_error": (C.c_char_p, []), "ufm_built_arch": (C.c_char_p, [])}
 
 
