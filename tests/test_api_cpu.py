@@ -303,3 +303,23 @@ def test_bench_gpus_2_end_to_end_on_a_box_without_a_gpu_fails_in_the_ranks_not_i
     assert r.returncode != 0
     assert "bench.py needs an MI355X" in r.stderr and "launch with torch.distributed.run" not in r.stderr
     assert "parent touched the GPU: False" in r.stderr
+
+
+def test_interleave_split_layout_and_block_eligibility():
+    """Round 6: UFM_BF16X2_IL = [rows][C / 32][hi 32 | lo 32] (hip.interleave_split: a plain re-layout of the (2, rows, C) planes), and the rule that decides
+    which transformer blocks run their Linears on it in numerics "precise" (engine._il_ok: N % 256 == 0, K % 32 == 0, K >= 64 for all four)."""
+    import torch
+    from ufm_amd import engine, hip
+
+    planes = torch.arange(2 * 3 * 64, dtype=torch.float32).view(2, 3, 64).to(torch.bfloat16)
+    il = hip.interleave_split(planes)
+    assert il.shape == (3, 2, 2, 32) and il.is_contiguous()
+    for row in range(3):
+        for chunk in range(2):
+            assert torch.equal(il[row, chunk, 0], planes[0, row, 32 * chunk : 32 * chunk + 32])  # hi half of the chunk
+            assert torch.equal(il[row, chunk, 1], planes[1, row, 32 * chunk : 32 * chunk + 32])  # lo half right behind it
+    L = torch.nn.Linear
+    assert engine._il_ok(L(1024, 3072), L(1024, 1024), L(1024, 4096), L(4096, 1024))       # the encoder's block
+    assert engine._il_ok(L(768, 2304), L(768, 768), L(768, 3072), L(3072, 768))            # the info-sharing block
+    assert not engine._il_ok(L(128, 384), L(128, 128), L(128, 512), L(512, 128))           # the tiny test model: planar path
+    assert not engine._il_ok(L(32, 256))                                                   # K below two K-tiles

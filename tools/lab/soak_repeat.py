@@ -59,3 +59,20 @@ def soak_big(model, tag):
     bad = sum(0 if torch.equal(model.predict_correspondences_batched(src, tgt).flow.flow_output, f0) else 1 for _ in range(max(4, REPS // 10)))
     print(f"{tag}: {bad} of {max(4, REPS // 10)} repeats differ", flush=True)
 soak_big(m, "UFM-Base 1036^2 B=1 precise (10 954-token joint attention on the round-5 kernel)")
+# round 6: the row-window halo convolution (counted waits of its own, buffer-load zero padding) on NON-square maps with tiles across image boundaries --
+# the reference's class-default resolution (420 x 560: 120 x 160 / 60 x 80 head maps), 1080 x 810 inputs through the GPU antialias resize; the
+# precise soak above already runs the interleaved bf16x3 Linear layers and the fixed-reference attention
+del m
+cfg = ufm_amd.ufm_base_config()
+cfg.pop("inference_resolution")
+m = ufm_amd.UniFlowMatchConfidence(**cfg).eval(); init_weights_(m, 0); m = m.to("cuda")
+def soak_default(model, B, tag):
+    g = torch.Generator().manual_seed(11)
+    src = torch.randint(0, 256, (B, 810, 1080, 3), dtype=torch.uint8, generator=g).cuda()
+    tgt = torch.randint(0, 256, (B, 810, 1080, 3), dtype=torch.uint8, generator=g).cuda()
+    o = model.predict_correspondences_batched(src, tgt)
+    f0 = o.flow.flow_output.clone()
+    bad = sum(0 if torch.equal(model.predict_correspondences_batched(src, tgt).flow.flow_output, f0) else 1 for _ in range(REPS))
+    print(f"{tag}: {bad} of {REPS} repeats differ", flush=True)
+soak_default(m, 8, "UFM-Base class-default 420x560 B=8 fast (halo convolution on 120x160 / 60x80 maps)")
+soak_default(m, 3, "UFM-Base class-default 420x560 B=3 fast")
