@@ -34,7 +34,7 @@ for d in ("pmc_step_fetch", "pmc_step_write", "pmc_step_util"):
             if fam:
                 acc[fam][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 if fam in ("ufm_gemm_bf16", "ufm_conv2d_nhwc_bf16x3"):
-                    short = r["Kernel_Name"].split("(")[0].replace("(anonymous namespace)::", "").replace("void ", "")[:60]
+                    short = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:70]
                     by_grid[(fam, short, r.get("Grid_Size", r.get("Grid_Size_X", "?")))][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for fam, d in acc.items():
@@ -75,6 +75,9 @@ res["_meta"] = {"csrc_sha256": csrc_sha256(ROOT), "commit_at_summarise_time": co
                 "command": "tools/pmc_traffic.sh (bench.py --steps 2 --warmup 1 --micro-batches 1, separate --pmc passes)"}
 json.dump(res, open(out_path, "w"), indent=1)
 for k, v in res.items():
-    if k == "_meta":
+    if k.startswith("_"):
         continue
     print(k, {a: (round(b, 3) if isinstance(b, float) and b < 10 else int(b)) for a, b in v.items()})
+print("by kernel and grid (read GB per step, top 16):")
+for e in tab[:16]:
+    print("  ", e)
