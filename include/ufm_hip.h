@@ -372,7 +372,9 @@ int ufm_gemm_bf16x3(const uint16_t* A, const uint16_t* W, int M, int N, int K, c
 int ufm_gemm_bf16x3_il(const uint16_t* A, const uint16_t* W, int M, int N, int K, const float* bias, int act, const float* gamma,
                        const float* res, void* out, int out_dtype, const uint16_t* zero_page, void* stream);
 int ufm_attention_bf16x3(const uint16_t* qkv, uint16_t* out, int B, int N, int H, float scale, void* stream);
-/* Round 6: the same attention with O stored INTERLEAVED (UFM_BF16X2_IL: [B*N][H*64 / 32][hi 32 | lo 32]) -- the A operand of ufm_gemm_bf16x3_il. */
+/* Round 6: the same attention with O stored INTERLEAVED (UFM_BF16X2_IL: [B*N][H*64 / 32][hi 32 | lo 32]) -- the A operand of ufm_gemm_bf16x3_il.
+ * scale == 0: the Q columns of qkv arrive pre-scaled by softmax_scale * log2(e) (the QKV Linear's gamma does it before the split store), and the
+ * kernel applies no per-score multiply (the convention of ufm_attention_bf16_strided / ufm_cross_attention_bf16). */
 int ufm_attention_bf16x3_il(const uint16_t* qkv, uint16_t* out, int B, int N, int H, float scale, void* stream);
 
 /* Bilinear resize, align_corners=True, NHWC fp32 ([U] FeatureFusionBlock x2 upsample,

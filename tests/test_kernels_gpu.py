@@ -1198,6 +1198,16 @@ def test_attention_bf16x3_interleaved_output(hip, B, N, H):
     il = torch.full((B * N, H * 2, 2, 32), 7.0, device=DEV, dtype=torch.bfloat16)
     hip.attention_x3(qkv, il, B, N, H, 0.125, out_interleaved=True)
     assert torch.equal(il.view(torch.int16), hip.interleave_split(planar).view(torch.int16))
+    # scale = 0: the Q columns pre-scaled by softmax_scale * log2(e) (what the engine's QKV epilogue does in "precise"), no multiply per score
+    # in the kernel -- the same softmax against the fp64 statement on the ORIGINAL q
+    q0 = unsplit(qkv.cpu())
+    ref = attn_ref(q0, B, N, H, 0.125)
+    pre = q0.clone()
+    pre[:, : H * 64] *= 0.125 * 1.4426950408889634
+    il2 = torch.full((B * N, H * 2, 2, 32), 7.0, device=DEV, dtype=torch.bfloat16)
+    hip.attention_x3(split(pre).to(DEV), il2, B, N, H, 0.0, out_interleaved=True)
+    got = unsplit(il2.permute(2, 0, 1, 3).reshape(2, B * N, H * 64).cpu()).double()
+    assert (got - ref).abs().max().item() <= 1e-4
 
 
 @pytest.mark.parametrize("rows,D", [(37, 256), (1370, 1024), (2738, 768)])

@@ -274,9 +274,10 @@ extern "C" int ufm_attention_bf16x3(const uint16_t* qkv, uint16_t* out, int B, i
 extern "C" int ufm_attention_bf16x3_il(const uint16_t* qkv, uint16_t* out, int B, int N, int H, float scale, void* stream) {
     UFM_REQUIRE(qkv && out, "ufm_attention_bf16x3_il: null pointer");
     UFM_REQUIRE(B > 0 && N > 0 && H > 0 && (int64_t)((N + QB - 1) / QB) * H * B < (1ll << 31), "ufm_attention_bf16x3_il: bad shape B=%d N=%d H=%d", B, N, H);
-    UFM_REQUIRE(scale > 0.0f, "ufm_attention_bf16x3_il: scale must be positive");
+    UFM_REQUIRE(scale >= 0.0f, "ufm_attention_bf16x3_il: scale must be positive, or 0 for q pre-scaled by softmax_scale * log2(e)");
     UFM_REQUIRE(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 8) == 0, "ufm_attention_bf16x3_il: misaligned pointer");
     UFM_REQUIRE(!ufm_attn_x3_use_old() && (long long)N * 3 * H * 64 * 2 < (1ll << 31), "ufm_attention_bf16x3_il: the interleaved output exists in the LDS-DMA kernel only (variant bit 1 clear, N * 3 H * 128 B < 2 GiB)");
+    UFM_REQUIRE(scale > 0.0f || ufm_attn_x3_fixref(), "ufm_attention_bf16x3_il: scale == 0 (pre-scaled q) needs the fixed-reference kernel (variant bits 2 and 3 clear)");
     const long long rows = (long long)B * N;
     ufm_launch_attn_x3_pw(qkv, 3 * H * 64, rows * 3 * H * 64, qkv + H * 64, qkv + 2 * H * 64, 3 * H * 64, rows * 3 * H * 64, out, H * 64, rows * H * 64, B, N, N, H,
                           scale * 1.44269504088896340736f, (hipStream_t)stream, ufm_attn_x3_waves(), 1, ufm_attn_x3_fixref());

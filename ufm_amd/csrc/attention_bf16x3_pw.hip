@@ -54,7 +54,9 @@ __device__ __forceinline__ unsigned lds_addr_of(const char* p) { return (unsigne
 // to that tile's maximum in a cold, wave-uniform path in front of P.V (any jump is handled: the tile's softmax is redone).  The bf16 kernel's scheme (attention_bf16_pw.hip); PMC put this kernel at 7.1 VALU instructions per MFMA,
 // issue-bound -- this takes 1.2 of them out.  The same softmax in exact arithmetic, other roundings: NOT bitwise the round-1 kernel
 // (FIXREF = false stays that, ufm_debug_set_attn_variant bit 1 or the ufm_attention_bf16x3 test hook selects it); tested against fp64.
-template <int NW, bool FIXREF = false>
+// PRESC (with FIXREF): q arrives pre-scaled by softmax_scale * log2(e) (the QKV Linear's epilogue multiplies the Q columns before the (hi, lo)
+// split, as the bf16 path does): P = exp2(S') with no multiply per score -- one more VALU instruction out of the issue-bound gap.
+template <int NW, bool FIXREF = false, bool PRESC = false>
 __global__ __launch_bounds__(NW * 64, 8 / NW) void attn_x3_pw_kernel(const uint16_t* __restrict__ qp_, int ldq, long long q_plane,
                                                             const uint16_t* __restrict__ kp_, const uint16_t* __restrict__ vp_, int ldkv, long long in_plane,
                                                             uint16_t* __restrict__ out, int ldo, long long out_plane, int Nq, int N, int H, float c, int out_il) {
@@ -176,8 +178,8 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void attn_x3_pw_kernel(const uint1
             if constexpr (J % 3 != 2) {
                 constexpr int P = (J / 3) * 2 + (J % 3), kt = P >> 3, r = 2 * (P & 7);
                 if constexpr (P == 0) lsum = 0.f;
-                const float p0 = __builtin_amdgcn_exp2f(st[kt][r] * c);
-                const float p1 = __builtin_amdgcn_exp2f(st[kt][r + 1] * c);
+                const float p0 = __builtin_amdgcn_exp2f(PRESC ? st[kt][r] : st[kt][r] * c);
+                const float p1 = __builtin_amdgcn_exp2f(PRESC ? st[kt][r + 1] : st[kt][r + 1] * c);
                 lsum += p0 + p1;
                 const unsigned h = pack_bf16x2(p0, p1);
                 pkh[r >> 1] = h;
@@ -413,6 +415,7 @@ int ufm_launch_attn_x3_pw(const uint16_t* q, int ldq, long long q_plane, const u
     const int nw = waves == 8 ? 8 : 4;
     const dim3 grid(((Nq + nw * 32 - 1) / (nw * 32)) * H * B), block(nw * 64);
     if (nw == 8) hipLaunchKernelGGL(attn_x3_pw_kernel<8>, grid, block, 0, stream, q, ldq, q_plane, k, v, ldkv, in_plane, out, ldo, out_plane, Nq, Nk, H, c, out_il);
+    else if (fixref && c == 0.0f) hipLaunchKernelGGL((attn_x3_pw_kernel<4, true, true>), grid, block, 0, stream, q, ldq, q_plane, k, v, ldkv, in_plane, out, ldo, out_plane, Nq, Nk, H, 1.0f, out_il);  // q pre-scaled
     else if (fixref) hipLaunchKernelGGL((attn_x3_pw_kernel<4, true>), grid, block, 0, stream, q, ldq, q_plane, k, v, ldkv, in_plane, out, ldo, out_plane, Nq, Nk, H, c, out_il);
     else hipLaunchKernelGGL(attn_x3_pw_kernel<4>, grid, block, 0, stream, q, ldq, q_plane, k, v, ldkv, in_plane, out, ldo, out_plane, Nq, Nk, H, c, out_il);
     return 0;

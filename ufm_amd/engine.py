@@ -134,7 +134,9 @@ class _Blk:
         # so the attention kernel works in the log2 domain with no per-score multiply and no extra rounding
         d = self.qkv.n // 3
         self.qscale = None
-        if wdt == torch.bfloat16 and not split:
+        # (round 6: the interleaved split path of "precise" pre-scales too -- the split store takes (hi, lo) of q * scale * log2(e), and
+        #  ufm_attention_bf16x3_il with scale = 0 exponentiates the scores as they are: one VALU instruction per score less in an issue-bound kernel)
+        if (wdt == torch.bfloat16 and not split) or il:
             self.qscale = torch.cat([torch.full((d,), 0.125 * LOG2E), torch.ones(2 * d)]).to(device=dev, dtype=torch.float32)
 
 
@@ -753,7 +755,7 @@ class Engine:
                 hip.layernorm(x, D, None, M, D, w.n1w, w.n1b, 1e-6, xn, split=x3, interleaved=il)
             self.linear(xn, w.qkv, M, qkv, gamma=w.qscale)
             if x3:
-                hip.attention_x3(qkv, ao, Bseq, N, heads, 0.125, out_interleaved=il)
+                hip.attention_x3(qkv, ao, Bseq, N, heads, 0.0 if (il and w.qscale is not None) else 0.125, out_interleaved=il)
             else:
                 hip.attention(qkv, ao, Bseq, N, heads, 0.0 if w.qscale is not None else 0.125)
             if defer:
