@@ -1480,6 +1480,8 @@ def test_conv2d_bf16x3_8phase_bit_identical(hip, B, H, W, Cin, Cout, k, stride, 
         (7, 19, 33, 32, 256, 0, 0, 1),      # Cin = 32: three windows (the minimum); (H - 2) W = 561; ragged last tile
         (1, 64, 32, 64, 512, 0, 0, 1),      # W = 32 (the minimum: one row end per fragment), two cout tiles
         (4, 40, 48, 128, 256, 0, 1, 2),     # a grouped launch (the two DPT heads in one grid): per-group windows, ragged per-group tiles
+        (1, 11, 32, 32, 256, 2, 0, 1),      # the eligibility boundary ((H - 2) W = 288 >= 272): ONE image of 352 pixels -- tile 1 is ragged and its windows run past the tensor's end
+        (2, 11, 32, 64, 256, 0, 1, 1),      # the same map twice: an image boundary INSIDE tile 1 and the tensor's end inside tile 2
     ],
 )
 def test_conv2d_bf16x3_halo_bit_identical(hip, B, H, W, Cin, Cout, act, nres, groups):
