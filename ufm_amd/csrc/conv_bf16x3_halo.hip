@@ -11,18 +11,20 @@
 //     [plane (hi, lo)][NRP row pieces of 16 px][64 B], NRP = 2 NF + 1, in two ping-pong buffers (68 KiB); tap (kh, kw) of output pixel j
 //     reads window pixel j + kw.  A "super-tile" = the three K-tiles of one window = 12 phases.
 //   * Borders.  Rows: window pixel e belongs to image row y0 + kh - 1, y0 = row of flat pixel m0 - 1 + e; it is a proper input of filter
-//     row kh iff that row lies in the same image (kh = 0: y0 != 0, kh = 2: y0 != H - 1) -- decided per window pixel when it is STAGED
-//     (zero page otherwise), exactly the zero padding of the gather.  Columns: output pixel x = 0 (kw = 0) / x = W - 1 (kw = 2) would read
+//     row kh iff that row lies in the same image (kh = 0: y0 != 0, kh = 2: y0 != H - 1) -- decided when the window is STAGED: the void
+//     pixels of a window are ONE scalar interval (the nearest image boundary +- a row), and a void lane issues its piece with an out-of-range buffer
+//     offset, which writes zeros to its LDS slot (tools/lab/buffer_lds_oob.hip) -- exactly the zero padding of the gather.  Columns: output pixel x = 0 (kw = 0) / x = W - 1 (kw = 2) would read
 //     the neighbouring row's end through the flat shift: those fragment rows are zeroed in registers, on the fragments that contain such a
 //     pixel only (wave-uniform bit test; a 16-pixel fragment holds a row boundary in 11 % of the cases at W = 148).  A zero operand is what
-//     the gather's zero page supplied: same products, same order.
+//     the gather's zero page supplied: same products, same order.  All operands come in by raw buffer loads to LDS (32-bit lane offsets into
+//     wave-uniform descriptors): no 64-bit lane addresses, no per-lane flag registers -- the kernel must be spill-free (a scratch reload counts in vmcnt).
 //   * K order, product order (wl*ah, wh*al, wh*ah), wave layout, W half-tiles, the two-group ping-pong schedule and the epilogue are those of
 //     conv_bf16x3_8ph.hip: results are BIT-IDENTICAL (tests/test_kernels_gpu.py::test_conv2d_bf16x3_halo_bit_identical).
 //   * Vector-memory schedule of one wave over the 12 phases of super-tile u (l_end of phase p): p even: the 2 pieces of a W half-tile as
 //     before (W-hi(t+1) at I = 0, W-lo(t+2) at I = 2); p = 1, 3: hi + lo piece of window u + 1's row pieces w and 8 + w; p = 5, 7 (NF = 8
-//     only): hi / lo of row piece 16 (its 2 real pixels: wave 0; the other waves' pieces go to a 1-KiB scrap area from the zero page so that
-//     every wave counts the same operations).  6 instead of 12 X operations per wave and filter row, 34 instead of 96 KiB.
-//     Counted waits (all compile-time, table C below): at even p the W half-tile issued four phases earlier = everything but the
+//     only): hi / lo of row piece 16 (its 2 real pixels: wave 0; the other waves' pieces go to a 1-KiB scrap area with an out-of-range offset so that
+//     every wave counts the same operations; the same happens to every operation scheduled past the end of the K range).  6 instead of 12 X operations per wave and filter row, 34 instead of 96 KiB.
+//     Counted waits (all compile-time, `Sched` below): at even p the W half-tile issued four phases earlier = everything but the
 //     operations of phases p-3..p; at p = 11 window u + 1 = everything but the operations issued since its last piece.
 //   * Hazards.  RAW: a window is waited for by every wave at l_end(12 u + 11) and first read at the start of phase 12 (u + 1), i.e. after
 //     group 0 passed its mma barrier of phase 12 u + 11, which group 1 reaches only behind ITS l_end(12 u + 11) wait (the half-tile rule of
