@@ -208,11 +208,19 @@ def test_bench_line_keeps_every_judged_scalar_in_its_last_2000_characters():
             "latency_b1_ms": {"eager_p50": 9.4, "iters": 20, "batch": 1, "graph_replay_p50": 9.0, "graph_bitwise_equals_eager": True},
             "precise_mode": {"value": 103.7, "unit": "pairs/s", "ms_per_step": 77.1, "flow_max_abs": 1.2e-4, "covis_max_abs": 2e-5, "numerics": "n" * 200, "kernels": {k: v for k, v in kernels.items()}},
             "parity_mode": {"value": 33.7, "unit": "pairs/s", "ms_per_step": 237.0, "flow_max_abs": 6.1e-5, "numerics": "p" * 100}}
+    # round 5 / 6 legs: the side configurations, the in-kernel clock and the per-family table of the two-stream dispatch
+    side = lambda v: {"workload": "w" * 120, "value": v, "unit": "pairs/s", "ms_per_step": 38.5, "steps": 6, "numerics": "fast",  # noqa: E731
+                      "mfma_families": {"gemm_bf16": {"ms": 19.1, "frac": 0.35}, "attention_bf16": {"ms": 6.1, "frac": 0.31}, "conv2d_nhwc_bf16x3": {"ms": 10.2, "frac": 0.4}}}
+    line.update(config4=side(207.6), config5=side(37.5), default_res=side(256.9))
+    line["roofline"].update(clock_ghz=1.92, frac_at_clock=0.46, clock_source="c" * 300)
+    line["pipeline_kernels"] = {"families": {k.replace("ufm_", ""): {"launches": 100, "sum_ms": 30.0, "frac_while_sharing": 0.2016} for k in kernels if k != "ufm_layernorm"},
+                                "sum_of_launch_ms": 72.5, "wall_ms_per_step": 35.07, "overlap_factor": 2.067, "dispatch": "d" * 120, "how": "h" * 150}
     text = json.dumps(bench.order_line(line, 8))
     assert len(text) > 6000  # the test is only meaningful on a line longer than the tail
     tail = text[-2000:]
     for needle in ('"summary"', '"value": 216.2', '"roofline_frac": 0.34', '"attention_frac": 0.3', '"precise": {"pairs_per_s": 103.7, "flow_max_abs": 0.00012}', '"parity": {"pairs_per_s": 33.7',
-                   '"fast_flow_max_abs": 0.035', '"graph_replay_p50": 9.0', '"end_to_end_frac"', '"attention_share_frac"', '"gemm_shape_frac"', '"cpu_pairs_per_s": 0.144'):
+                   '"fast_flow_max_abs": 0.035', '"graph_replay_p50": 9.0', '"end_to_end_frac"', '"attention_share_frac"', '"gemm_shape_frac"', '"cpu_pairs_per_s": 0.144',
+                   '"config4": {"pairs_per_s": 207.6', '"config5": {"pairs_per_s": 37.5', '"default_res": {"pairs_per_s": 256.9', '"pipeline_overlap_factor": 2.067', '"clock_ghz": 1.92'):
         assert needle in tail, needle
     back = json.loads(text)  # still one valid JSON object with the contract's keys
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
